@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+GOLDEN_CASES = [
+    "aniso_miro_7_rgb_disk",
+    "chm_orange_rgb_disk",
+    "vch_silk_blue_rgb_disk",
+    "aniso_miro_7_rgb_spherical",
+    "chm_orange_rgb_spherical",
+    "bsdf_3_spherical",
+    "aniso_miro_7_rgb_spherical_complex",
+]
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_case(stem):
+    import numpy as np
+    from bsdf_diffusion_sampling_amd import weights as W
+
+    g = np.load(os.path.join(GOLDEN, stem + ".npz"))
+    fw = W.load(os.path.join(W.DATA_DIR, stem + ".bsdfw"))
+    return g, fw
+
+
+@pytest.fixture(params=GOLDEN_CASES)
+def golden_case(request):
+    g, fw = load_case(request.param)
+    return request.param, g, fw
