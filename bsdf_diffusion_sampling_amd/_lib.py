@@ -1,0 +1,90 @@
+"""ctypes binding of the C-ABI shared library ``libbsdfd.so`` (include/bsdfd.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There
+is NO fallback: if the library is missing or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libbsdfd.so")
+SRC_PATH = os.path.join(_HERE, "csrc", "bsdfd.hip")
+INCLUDE_DIR = os.path.join(ROOT, "include")
+
+PREC_DEFAULT, PREC_F32, PREC_SPLIT3, PREC_F16 = 0, 1, 2, 3
+PRECISIONS = {"default": PREC_DEFAULT, "f32": PREC_F32, "split3": PREC_SPLIT3, "f16": PREC_F16}
+PLUGIN_MEASURED, PLUGIN_FULLSPHERE = 0, 1
+
+# every symbol include/bsdfd.h declares
+EXPORTS = (
+    "bsdfd_create", "bsdfd_create_from_file", "bsdfd_destroy", "bsdfd_get_info",
+    "bsdfd_flops_per_query", "bsdfd_network_sampling", "bsdfd_network_pdf",
+    "bsdfd_plugin_sample", "bsdfd_plugin_pdf", "bsdfd_flow_samples_only",
+    "bsdfd_set_profiling", "bsdfd_last_kernel_ms", "bsdfd_last_error", "bsdfd_version",
+)
+
+
+class Desc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("domain", "width", "n_hidden", "pe_bands", "base_hidden",
+                                         "base_pe_bands", "precision", "reserved")] + \
+               [(n, C.POINTER(C.c_float)) for n in ("w_in", "w_hidden", "w_out", "base_w1", "base_b1",
+                                                    "base_w2", "base_b2")]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile libbsdfd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    hdr = os.path.join(INCLUDE_DIR, "bsdfd.h")
+    if (not force and os.path.exists(LIB_PATH)
+            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(SRC_PATH), os.path.getmtime(hdr))):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+           "-I", INCLUDE_DIR, SRC_PATH, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the library (raises if it has not been built — no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, fp = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
+    L.bsdfd_create.argtypes = [C.POINTER(Desc), C.POINTER(vp)]
+    L.bsdfd_create_from_file.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    L.bsdfd_destroy.argtypes = [vp]
+    L.bsdfd_destroy.restype = None
+    L.bsdfd_get_info.argtypes = [vp] + [C.POINTER(i32)] * 4
+    L.bsdfd_flops_per_query.argtypes = [vp, i32]
+    L.bsdfd_flops_per_query.restype = i64
+    L.bsdfd_network_sampling.argtypes = [vp, fp, fp, u64, u64, i64, i32, fp, fp, vp]
+    L.bsdfd_network_pdf.argtypes = [vp, fp, fp, i64, i32, fp, vp]
+    L.bsdfd_plugin_sample.argtypes = [vp, i32, fp, fp, u64, u64, i64, i32, fp, fp, vp]
+    L.bsdfd_plugin_pdf.argtypes = [vp, i32, fp, fp, i64, i32, fp, vp]
+    L.bsdfd_flow_samples_only.argtypes = [vp, fp, fp, i64, i32, fp, vp]
+    L.bsdfd_set_profiling.argtypes = [vp, i32]
+    L.bsdfd_last_kernel_ms.argtypes = [vp]
+    L.bsdfd_last_kernel_ms.restype = C.c_float
+    L.bsdfd_last_error.restype = C.c_char_p
+    L.bsdfd_version.restype = C.c_char_p
+    for name in EXPORTS:
+        getattr(L, name)  # AttributeError if a declared symbol is missing
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise RuntimeError(f"bsdfd error {rc}: {lib().bsdfd_last_error().decode()}")

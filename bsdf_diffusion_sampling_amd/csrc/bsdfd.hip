@@ -1,0 +1,929 @@
+// bsdfd.hip — MI355X (gfx950 / CDNA4) implementation of the neural-BSDF flow sampler.
+//
+// One fused kernel per call evaluates, for every query, the whole hot path of
+// fzy28/BSDF_diffusion_sampling (paths relative to the reference root):
+//   positional encoding            rendering/utils/model.py:9-57
+//   conditional base density       model.py:374-398 (disk), :277-317 (spherical)
+//   velocity net, T Euler steps    model.py:479-501 / :422-446 / :449-477
+//   2x2 Jacobian determinant       rendering/utils/mlp_brdf_sampling.py:17-51,:69-103,:106-181
+//   domain warps and guards        rendering/brdf_measured_{disk,spherical}.py, bsdf_myresult.py
+//
+// Mapping to the hardware (DESIGN.md has the long version):
+//   * a wave64 owns a tile of 16 queries; lane = (g = lane>>4, q = lane&15) holds, for
+//     query q, hidden units {16m + 4g + r}.  That is exactly the C/D layout of the
+//     16x16 MFMA shapes, and — because the K index of a contraction may be permuted
+//     freely as long as A and B agree — also the B-operand layout of the NEXT layer:
+//     the weights are pre-permuted on the host so activations never leave registers
+//     between layers (no LDS round trip, no cross-lane traffic).
+//   * the layer contraction is D[unit, query] = sum_k W[unit, k] * H[k, query]; the three
+//     vectors that flow through every layer (activation h and the two Jacobian tangents
+//     t0 = dh/dx0, t1 = dh/dx1 — forward-mode equivalent of the reference's two
+//     backward() calls) share each weight fragment.
+//   * the conditioning part of layer 1 (W1[:, PE(omega_i)]) is constant across the T
+//     steps: it is computed once per query and used as the C-in accumulator of the
+//     per-step layer-1 MFMA.
+//   * weights live in LDS as ready-made MFMA A-fragments (one ds_read_b128 per use).
+//   * precision of the contractions: exact fp32 MFMA (16x16x4), or fp16 MFMA (16x16x32)
+//     with hi+lo operand splitting (3 products, fp32 accumulate), or plain fp16.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bsdfd.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int PE_BANDS = 5;       // rendering/brdf_measured_disk.py:43 (POSITIONAL_ENCODING_BASIS_NUM=5)
+constexpr int BASE_PE_BANDS = 3;  // :49
+constexpr int BASE_HIDDEN = 16;
+constexpr int PE_SLABS = PE_BANDS + 1;  // K=4 slabs: one per band (sin/cos x 2 dims) + the raw (y0,y1) slab
+constexpr float LO_SCALE = 2048.0f;     // lo halves are stored x2^11 so they stay in fp16's normal range
+constexpr float LO_INV = 1.0f / 2048.0f;
+
+enum { OP_SAMPLE = 0, OP_PDF = 1, OP_SAMPLES_ONLY = 2 };
+enum { IO_OPERATOR = 0, IO_PLUGIN = 1, IO_PLUGIN_FULLSPHERE = 2 };
+
+struct ImgLayout {  // byte offsets into the weight image (identical in global memory and LDS)
+    int win, wc, wh, wh_lo, wo, bw1, bb1, bw2, bb2, total;
+};
+
+struct KParams {
+    const char* img;
+    ImgLayout L;
+    const float* in_a;   // operator: omega_i [N,2]   plugin: wi [N,3]
+    const float* in_b;   // sample: x0 [N,2] or null  pdf: omega_o [N,2] / wo [N,3]
+    float* out_x;        // sample: x [N,2] / wo [N,3]
+    float* out_pdf;      // [N]
+    long long N;
+    int T;
+    int n_hidden;
+    int op;
+    int io;
+    unsigned long long seed, offset;
+};
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// SiLU and its derivative from one sigmoid: h = z*s, g = s*(1 + z*(1-s)) = s + h*(1-s).
+__device__ __forceinline__ void silu_grad(float z, float& h, float& g) {
+    const float e = __expf(-z);
+    const float s = __frcp_rn(1.0f + e);
+    h = z * s;
+    g = fmaf(h, 1.0f - s, s);
+}
+__device__ __forceinline__ float silu(float z) { return z * __frcp_rn(1.0f + __expf(-z)); }
+
+__device__ __forceinline__ float sel4(int g, float a0, float a1, float a2, float a3) {
+    return g == 0 ? a0 : (g == 1 ? a1 : (g == 2 ? a2 : a3));
+}
+
+// Philox4x32-10 counter-based RNG (Salmon et al., SC'11); stream = (seed; query index, draw index).
+__device__ __forceinline__ void philox4x32(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2,
+                                           unsigned c3, unsigned out[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01_open(unsigned x) {  // (0, 1]
+    return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+// log I0(kappa): the two polynomials of torch.distributions.von_mises._log_modified_bessel_fn
+// (torch 2.10; call site rendering/utils/model.py:314), split at 3.75.
+__device__ __forceinline__ float log_i0(float k) {
+    if (k < 3.75f) {
+        float y = k * (1.0f / 3.75f);
+        y = y * y;
+        float p = 0.0045813f;
+        p = fmaf(p, y, 0.0360768f); p = fmaf(p, y, 0.2659732f); p = fmaf(p, y, 1.2067492f);
+        p = fmaf(p, y, 3.0899424f); p = fmaf(p, y, 3.5156229f); p = fmaf(p, y, 1.0f);
+        return logf(p);
+    }
+    const float y = 3.75f / k;
+    float p = 0.00392377f;
+    p = fmaf(p, y, -0.01647633f); p = fmaf(p, y, 0.02635537f); p = fmaf(p, y, -0.02057706f);
+    p = fmaf(p, y, 0.00916281f); p = fmaf(p, y, -0.00157565f); p = fmaf(p, y, 0.00225319f);
+    p = fmaf(p, y, 0.01328592f); p = fmaf(p, y, 0.39894228f);
+    return k - 0.5f * logf(k) + logf(p);
+}
+
+__device__ __forceinline__ float softplus(float x) {  // nn.Softplus(beta=1, threshold=20)
+    return x > 20.0f ? x : log1pf(expf(x));
+}
+
+// Best & Fisher rejection sampler for VonMises(mu, kappa); the proposal constant is formed
+// in fp64 as torch does (torch/distributions/von_mises.py::_rejection_sample) because
+// tau - sqrt(2 tau) cancels catastrophically in fp32 for small kappa.
+__device__ float von_mises_sample(float mu, float kappa, unsigned k0, unsigned k1, unsigned q_lo,
+                                  unsigned q_hi) {
+    const double kd = (double)kappa;
+    double rr;
+    if (kd < 1e-5) {
+        rr = 1.0 / kd + kd;
+    } else {
+        const double tau = 1.0 + sqrt(1.0 + 4.0 * kd * kd);
+        const double rho = (tau - sqrt(2.0 * tau)) / (2.0 * kd);
+        rr = (1.0 + rho * rho) / (2.0 * rho);
+    }
+    const float r = (float)rr;
+    float x = 0.0f;
+    for (unsigned it = 0; it < 256u; ++it) {
+        unsigned u[4];
+        philox4x32(k0, k1, q_lo, q_hi, it + 1u, 0x564d6973u, u);  // "VMis"
+        const float u1 = u01_open(u[0]), u2 = u01_open(u[1]), u3 = u01_open(u[2]);
+        const float z = cospif(u1);
+        const float f = (1.0f + r * z) / (r + z);
+        const float c = kappa * (r - f);
+        const bool accept = (c * (2.0f - c) - u2 > 0.0f) || (logf(c / u2) + 1.0f - c >= 0.0f);
+        if (accept) {
+            const float a = acosf(fminf(fmaxf(f, -1.0f), 1.0f));
+            x = (u3 - 0.5f) < 0.0f ? -a : a;
+            break;
+        }
+    }
+    const float two_pi = 6.28318530717958647692f, pi = 3.14159265358979323846f;
+    float w = fmodf(x + pi + mu, two_pi);
+    if (w < 0.0f) w += two_pi;
+    return w - pi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The fused flow kernel.
+//   DOMAIN : BSDFD_DOMAIN_*            NM : width/16 (2 or 4)
+//   PREC   : BSDFD_PREC_F32 / SPLIT3 / F16      JAC : track the Jacobian determinant
+// ---------------------------------------------------------------------------------------------
+template <int DOMAIN, int NM, int PREC, bool JAC>
+__global__ __launch_bounds__(512) void flow_kernel(const KParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(p.img);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = threadIdx.x; i < p.L.total / 16; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    constexpr int KC = NM / 2;  // K chunks of 32 for the fp16 MFMA
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4;
+    const int q = lane & 15;
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+
+    const float* Lwin = reinterpret_cast<const float*>(smem + p.L.win);
+    const float* Lwc = reinterpret_cast<const float*>(smem + p.L.wc);
+    const char* Lwh = smem + p.L.wh;
+    const char* Lwh_lo = smem + p.L.wh_lo;
+    const char* Lwo = smem + p.L.wo;
+    const float* Lbw1 = reinterpret_cast<const float*>(smem + p.L.bw1);
+    const float* Lbb1 = reinterpret_cast<const float*>(smem + p.L.bb1);
+    const float* Lbw2 = reinterpret_cast<const float*>(smem + p.L.bw2);
+    const float* Lbb2 = reinterpret_cast<const float*>(smem + p.L.bb2);
+
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    float win[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) win[m] = Lwin[m * 64 + lane];
+
+    // layer-1 pre-activations of the constant tangents: d/dx0 (both domains), d/dx1 (disk)
+    f32x4 zt0c[NM], zt1c[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+        zt0c[m] = mfma4(win[m], g == 0 ? 1.0f : 0.0f, zero4);
+        zt1c[m] = mfma4(win[m], g == 1 ? 1.0f : 0.0f, zero4);
+    }
+
+    const bool reverse = (p.op == OP_PDF);
+    const float invT = (float)(1.0 / (double)p.T);
+    const float cstep = reverse ? -invT : invT;
+    const long long ntiles = (p.N + 15) / 16;
+
+    for (long long tile = (long long)blockIdx.x * waves_per_block + wave; tile < ntiles;
+         tile += (long long)gridDim.x * waves_per_block) {
+        const long long qi_raw = tile * 16 + q;
+        const bool valid = qi_raw < p.N;
+        const long long qi = valid ? qi_raw : p.N - 1;
+
+        // ---------------- inputs: condition (y0,y1) and, for pdf, the outgoing point -------------
+        float y0, y1, wi_z = 1.0f;
+        float xs0 = 0.f, xs1 = 0.f, wo_z = 1.0f, wo_sin = 1.0f;
+        if (p.io == IO_OPERATOR) {
+            const float2 c2 = reinterpret_cast<const float2*>(p.in_a)[qi];
+            y0 = c2.x; y1 = c2.y;
+            if (p.op == OP_PDF || p.in_b != nullptr) {
+                const float2 b2 = reinterpret_cast<const float2*>(p.in_b)[qi];
+                xs0 = b2.x; xs1 = b2.y;
+            }
+        } else {
+            const float wx = p.in_a[qi * 3 + 0], wy = p.in_a[qi * 3 + 1], wz = p.in_a[qi * 3 + 2];
+            wi_z = wz;
+            if (DOMAIN == BSDFD_DOMAIN_DISK) {
+                y0 = wx; y1 = wy;  // rendering/brdf_measured_disk.py:66-67
+            } else {               // cart_to_spher, rendering/brdf_measured_spherical.py:35-39
+                const float r = sqrtf(wx * wx + wy * wy + wz * wz);
+                y0 = acosf(wz / (r + 1e-8f));
+                y1 = atan2f(wy, wx);
+            }
+            if (p.op == OP_PDF) {
+                const float ox = p.in_b[qi * 3 + 0], oy = p.in_b[qi * 3 + 1], oz = p.in_b[qi * 3 + 2];
+                wo_z = oz;
+                wo_sin = sqrtf(ox * ox + oy * oy);  // Mitsuba Frame3f::sin_theta
+                if (DOMAIN == BSDFD_DOMAIN_DISK) {
+                    xs0 = ox; xs1 = oy;
+                } else {
+                    const float r = sqrtf(ox * ox + oy * oy + oz * oz);
+                    xs0 = acosf(oz / (r + 1e-8f));
+                    xs1 = atan2f(oy, ox);
+                }
+            } else if (p.in_b != nullptr) {
+                const float2 b2 = reinterpret_cast<const float2*>(p.in_b)[qi];
+                xs0 = b2.x; xs1 = b2.y;
+            }
+        }
+
+        // ---------------- positional encoding, distributed over the 4 lanes of a query -----------
+        // lane g evaluates (dim = g&1, fn = g>>1 ? cos : sin) for every band: slab b of the K=4
+        // contraction is [sin(2^b y0), sin(2^b y1), cos(2^b y0), cos(2^b y1)] = PE block b.
+        const float ysel = (g & 1) ? y1 : y0;
+        float pe[PE_BANDS];
+#pragma unroll
+        for (int b = 0; b < PE_BANDS; ++b) {
+            float sv, cv;
+            sincosf(ysel * (float)(1 << b), &sv, &cv);
+            pe[b] = (g >> 1) ? cv : sv;
+        }
+        const float yslab = g == 0 ? y0 : (g == 1 ? y1 : 0.0f);
+
+        // conditioning part of layer 1, constant across the Euler steps
+        f32x4 cacc[NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            f32x4 a = zero4;
+#pragma unroll
+            for (int s = 0; s < PE_BANDS; ++s) a = mfma4(Lwc[(m * PE_SLABS + s) * 64 + lane], pe[s], a);
+            cacc[m] = mfma4(Lwc[(m * PE_SLABS + PE_BANDS) * 64 + lane], yslab, a);
+        }
+
+        // ---------------- base-density net: PE_3 -> 16 (SiLU) -> 4 -------------------------------
+        f32x4 bo;
+        {
+            f32x4 bz = *reinterpret_cast<const f32x4*>(Lbb1 + lane * 4);
+#pragma unroll
+            for (int s = 0; s < BASE_PE_BANDS; ++s) bz = mfma4(Lbw1[s * 64 + lane], pe[s], bz);
+            bz = mfma4(Lbw1[BASE_PE_BANDS * 64 + lane], yslab, bz);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(Lbw2 + lane * 4);
+            bo = *reinterpret_cast<const f32x4*>(Lbb2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bo = mfma4(w2[r], silu(bz[r]), bo);
+        }
+        // bo = (loc0, loc1, ls0, ls1) disk | (loc, log_scale, mu, kappa_raw) spherical
+        float kappa = 0.0f;
+        if (DOMAIN == BSDFD_DOMAIN_SPHERICAL) kappa = softplus(bo[3]) + 1e-3f;
+
+        // ---------------- initial state ------------------------------------------------------------
+        float x0 = xs0, x1 = xs1;
+        if (p.op == OP_SAMPLE && p.in_b == nullptr) {  // draw x0 ~ D_base(. | omega_i) in-kernel
+            const unsigned long long ctr = p.offset + (unsigned long long)qi;
+            const unsigned k0 = (unsigned)p.seed, k1 = (unsigned)(p.seed >> 32);
+            unsigned u[4];
+            philox4x32(k0, k1, (unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0x476175u, u);  // "Gau"
+            const float rad = sqrtf(-2.0f * logf(u01_open(u[0])));
+            float sn, cs;
+            sincospif(2.0f * u01_open(u[1]), &sn, &cs);
+            if (DOMAIN == BSDFD_DOMAIN_DISK) {  // model.py:387-392
+                x0 = bo[0] + rad * cs * expf(bo[2]);
+                x1 = bo[1] + rad * sn * expf(bo[3]);
+            } else {                            // model.py:298-307
+                x0 = bo[0] + rad * cs * (expf(bo[1]) + 1e-3f);
+                x1 = von_mises_sample(bo[2], kappa, k0, k1, (unsigned)ctr, (unsigned)(ctr >> 32));
+            }
+        }
+
+        auto base_pdf = [&](float a0, float a1) -> float {
+            const float log2pi = 1.8378770664093453f;
+            if (DOMAIN == BSDFD_DOMAIN_DISK) {  // model.py:393-398
+                const float e0 = (a0 - bo[0]) / expf(bo[2]);
+                const float e1 = (a1 - bo[1]) / expf(bo[3]);
+                return expf(-log2pi - (bo[2] + bo[3]) - 0.5f * (e0 * e0 + e1 * e1));
+            } else {                            // model.py:308-317
+                const float e = (a0 - bo[0]) / (expf(bo[1]) + 1e-3f);
+                const float loggau = -0.5f * log2pi - bo[1] - 0.5f * e * e;
+                const float logvon = kappa * cosf(a1 - bo[2]) - log2pi - log_i0(kappa);
+                return expf(loggau + logvon);
+            }
+        };
+        float p0 = 1.0f;
+        if (p.op == OP_SAMPLE) p0 = base_pdf(x0, x1);
+
+        // ---------------- T explicit Euler steps ---------------------------------------------------
+        float acc = 1.0f;
+        for (int t = 0; t < p.T; ++t) {
+            const float alpha = reverse ? (float)(1.0 - (double)t / (double)p.T)
+                                        : (float)((double)t / (double)p.T);
+            f32x4 z[NM], zt0[NM], zt1[NM];
+            if (DOMAIN == BSDFD_DOMAIN_DISK) {
+                const float bs = sel4(g, x0, x1, alpha, 0.0f);
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    z[m] = mfma4(win[m], bs, cacc[m]);
+                    zt0[m] = zt0c[m];
+                    zt1[m] = zt1c[m];
+                }
+            } else {
+                float sp, cp;
+                sincosf(x1, &sp, &cp);  // net input [theta, sin phi, cos phi], mlp_brdf_sampling.py:119-121
+                const float bs = sel4(g, x0, sp, cp, alpha);
+                const float bt = sel4(g, 0.0f, cp, -sp, 0.0f);  // d/dphi of the input
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    z[m] = mfma4(win[m], bs, cacc[m]);
+                    zt0[m] = zt0c[m];
+                    if (JAC) zt1[m] = mfma4(win[m], bt, zero4);
+                }
+            }
+
+            f32x4 v = zero4, d0 = zero4, d1 = zero4;  // rows r=0,1: the two outputs
+            for (int layer = 0; layer < p.n_hidden; ++layer) {
+                const bool last = (layer == p.n_hidden - 1);
+                float h[NM][4], t0[NM][4], t1[NM][4];
+#pragma unroll
+                for (int m = 0; m < NM; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float gg;
+                        silu_grad(z[m][r], h[m][r], gg);
+                        if (JAC) {
+                            t0[m][r] = zt0[m][r] * gg;
+                            t1[m][r] = zt1[m][r] * gg;
+                        }
+                    }
+                if (PREC == BSDFD_PREC_F32) {
+                    if (!last) {
+                        const char* base = Lwh + (size_t)layer * NM * NM * 64 * 16;
+#pragma unroll
+                        for (int mo = 0; mo < NM; ++mo) {
+                            f32x4 a = zero4, a0 = zero4, a1 = zero4;
+#pragma unroll
+                            for (int m = 0; m < NM; ++m) {
+                                const f32x4 w = *reinterpret_cast<const f32x4*>(base + ((mo * NM + m) * 64 + lane) * 16);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    a = mfma4(w[r], h[m][r], a);
+                                    if (JAC) {
+                                        a0 = mfma4(w[r], t0[m][r], a0);
+                                        a1 = mfma4(w[r], t1[m][r], a1);
+                                    }
+                                }
+                            }
+                            z[mo] = a; zt0[mo] = a0; zt1[mo] = a1;
+                        }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) {
+                            const f32x4 w = *reinterpret_cast<const f32x4*>(Lwo + (m * 64 + lane) * 16);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                v = mfma4(w[r], h[m][r], v);
+                                if (JAC) {
+                                    d0 = mfma4(w[r], t0[m][r], d0);
+                                    d1 = mfma4(w[r], t1[m][r], d1);
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    // fp16 MFMA path: B fragments are the lane's own 8 values per K chunk, split
+                    // into hi = fp16(x) and lo = fp16((x - hi) * 2^11).
+                    f16x8 bh[KC], bl[KC], b0h[KC], b0l[KC], b1h[KC], b1l[KC];
+#pragma unroll
+                    for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float xv = h[2 * kc + (j >> 2)][j & 3];
+                            const _Float16 hv = (_Float16)xv;
+                            bh[kc][j] = hv;
+                            if (PREC == BSDFD_PREC_SPLIT3) bl[kc][j] = (_Float16)((xv - (float)hv) * LO_SCALE);
+                            if (JAC) {
+                                const float x0v = t0[2 * kc + (j >> 2)][j & 3], x1v = t1[2 * kc + (j >> 2)][j & 3];
+                                const _Float16 h0 = (_Float16)x0v, h1 = (_Float16)x1v;
+                                b0h[kc][j] = h0; b1h[kc][j] = h1;
+                                if (PREC == BSDFD_PREC_SPLIT3) {
+                                    b0l[kc][j] = (_Float16)((x0v - (float)h0) * LO_SCALE);
+                                    b1l[kc][j] = (_Float16)((x1v - (float)h1) * LO_SCALE);
+                                }
+                            }
+                        }
+                    if (!last) {
+                        const size_t lbase = (size_t)layer * NM * KC * 64 * 16;
+#pragma unroll
+                        for (int mo = 0; mo < NM; ++mo) {
+                            f32x4 a = zero4, a0 = zero4, a1 = zero4;     // hi*hi
+                            f32x4 ac = zero4, a0c = zero4, a1c = zero4;  // (hi*lo + lo*hi) * 2^11
+#pragma unroll
+                            for (int kc = 0; kc < KC; ++kc) {
+                                const size_t off = lbase + ((size_t)(mo * KC + kc) * 64 + lane) * 16;
+                                const f16x8 wh = *reinterpret_cast<const f16x8*>(Lwh + off);
+                                a = mfma16(wh, bh[kc], a);
+                                if (JAC) { a0 = mfma16(wh, b0h[kc], a0); a1 = mfma16(wh, b1h[kc], a1); }
+                                if (PREC == BSDFD_PREC_SPLIT3) {
+                                    const f16x8 wl = *reinterpret_cast<const f16x8*>(Lwh_lo + off);
+                                    ac = mfma16(wh, bl[kc], ac);
+                                    ac = mfma16(wl, bh[kc], ac);
+                                    if (JAC) {
+                                        a0c = mfma16(wh, b0l[kc], a0c); a0c = mfma16(wl, b0h[kc], a0c);
+                                        a1c = mfma16(wh, b1l[kc], a1c); a1c = mfma16(wl, b1h[kc], a1c);
+                                    }
+                                }
+                            }
+                            if (PREC == BSDFD_PREC_SPLIT3) {
+                                a += ac * LO_INV; a0 += a0c * LO_INV; a1 += a1c * LO_INV;
+                            }
+                            z[mo] = a; zt0[mo] = a0; zt1[mo] = a1;
+                        }
+                    } else {
+                        // output layer: A rows (i&3) = {Wout_hi[0], Wout_hi[1], Wout_lo[0], Wout_lo[1]}
+                        f32x4 e = zero4, e0 = zero4, e1 = zero4;     // A * hi
+                        f32x4 f = zero4, f0 = zero4, f1 = zero4;     // A * lo
+#pragma unroll
+                        for (int kc = 0; kc < KC; ++kc) {
+                            const f16x8 wo = *reinterpret_cast<const f16x8*>(Lwo + ((size_t)kc * 64 + lane) * 16);
+                            e = mfma16(wo, bh[kc], e);
+                            if (JAC) { e0 = mfma16(wo, b0h[kc], e0); e1 = mfma16(wo, b1h[kc], e1); }
+                            if (PREC == BSDFD_PREC_SPLIT3) {
+                                f = mfma16(wo, bl[kc], f);
+                                if (JAC) { f0 = mfma16(wo, b0l[kc], f0); f1 = mfma16(wo, b1l[kc], f1); }
+                            }
+                        }
+                        if (PREC == BSDFD_PREC_SPLIT3) {
+                            v[0] = e[0] + (e[2] + f[0]) * LO_INV;   v[1] = e[1] + (e[3] + f[1]) * LO_INV;
+                            d0[0] = e0[0] + (e0[2] + f0[0]) * LO_INV; d0[1] = e0[1] + (e0[3] + f0[1]) * LO_INV;
+                            d1[0] = e1[0] + (e1[2] + f1[0]) * LO_INV; d1[1] = e1[1] + (e1[3] + f1[1]) * LO_INV;
+                        } else {
+                            v = e; d0 = e0; d1 = e1;
+                        }
+                    }
+                }
+            }
+
+            // det(I + c*J) with the row convention of mlp_brdf_sampling.py:44-46; signed.
+            if (JAC) {
+                const float j00 = 1.0f + cstep * d0[0];
+                const float j01 = cstep * d1[0];
+                const float j10 = cstep * d0[1];
+                const float j11 = 1.0f + cstep * d1[1];
+                const float det = j00 * j11 - j01 * j10;
+                if (reverse) acc *= det; else acc /= det;
+            }
+            x0 += cstep * v[0];
+            x1 += cstep * v[1];
+        }
+
+        // ---------------- epilogue: density, warp, guards, store ------------------------------------
+        float pdf = 0.0f;
+        if (p.op == OP_SAMPLE) pdf = p0 * acc;
+        else if (p.op == OP_PDF) pdf = base_pdf(x0, x1) * acc;
+
+        const bool writer = valid && g == 0;
+        if (p.io == IO_OPERATOR) {
+            if (writer) {
+                if (p.op != OP_PDF) reinterpret_cast<float2*>(p.out_x)[qi] = make_float2(x0, x1);
+                if (p.op != OP_SAMPLES_ONLY) p.out_pdf[qi] = pdf;
+            }
+        } else if (p.op == OP_SAMPLE) {
+            float ox, oy, oz, pdf_sa;
+            if (DOMAIN == BSDFD_DOMAIN_DISK) {  // rendering/brdf_measured_disk.py:69-82
+                const float r2 = x0 * x0 + x1 * x1;
+                const bool ok = r2 < 0.995f;
+                ox = ok ? x0 : 0.0f; oy = ok ? x1 : 0.0f;
+                oz = sqrtf(fmaxf(1.0f - (ox * ox + oy * oy), 0.0f));
+                pdf_sa = (ok ? pdf : 0.0f) * oz;
+            } else {  // rendering/brdf_measured_spherical.py:79-91, bsdf_myresult.py:69-84
+                float st, ct, sp, cp;
+                sincosf(x0, &st, &ct);
+                sincosf(x1, &sp, &cp);
+                if (!(st > 0.00005f)) pdf = 0.0f;
+                if (p.io == IO_PLUGIN && !(ct > 0.0f)) pdf = 0.0f;
+                ox = cp * st; oy = sp * st; oz = ct;
+                const float inv = fminf(fmaxf(1.0f / sqrtf(ox * ox + oy * oy), 1.0f), 3.402823466e+38f);
+                pdf_sa = pdf * inv;
+            }
+            if (writer) {
+                p.out_x[qi * 3 + 0] = ox; p.out_x[qi * 3 + 1] = oy; p.out_x[qi * 3 + 2] = oz;
+                p.out_pdf[qi] = pdf_sa;
+            }
+        } else {
+            float pdf_sa;
+            if (DOMAIN == BSDFD_DOMAIN_DISK) {  // rendering/brdf_measured_disk.py:112-124
+                pdf_sa = (wi_z > 0.0f && wo_z > 0.0f) ? pdf * wo_z : 0.0f;
+            } else {
+                const float inv = fminf(fmaxf(1.0f / wo_sin, 1.0f), 3.402823466e+38f);
+                if (p.io == IO_PLUGIN) {  // rendering/brdf_measured_spherical.py:122-137
+                    if (!(sinf(xs0) > 0.00005f)) pdf = 0.0f;
+                    pdf_sa = (wi_z > 0.0f && wo_z > 0.0f) ? pdf * inv : 0.0f;
+                } else {                  // rendering/bsdf_myresult.py:115-133
+                    pdf_sa = pdf * inv;
+                }
+            }
+            if (writer) p.out_pdf[qi] = pdf_sa;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e__ = (expr);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail(BSDFD_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__));     \
+    } while (0)
+
+}  // namespace
+
+struct bsdfd_ctx {
+    int domain, width, n_hidden, precision, state_dim, in_dim;
+    int device, num_cu;
+    ImgLayout L;
+    char* d_img;
+    bool profiling;
+    hipEvent_t ev0, ev1;
+    bool ev_valid;
+};
+
+namespace {
+
+inline uint16_t f32_to_f16_bits(float x) {
+    const _Float16 h = (_Float16)x;
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
+}
+inline float f16_round(float x) { return (float)(_Float16)x; }
+
+// Build the weight image: every matrix is stored as ready-made MFMA A-fragments in the
+// lane order the kernel reads them (see the kernel header for the unit <-> (m, g, r) map).
+std::vector<char> build_image(const bsdfd_desc& d, int prec, ImgLayout& L) {
+    const int W = d.width, NM = W / 16, NH = d.n_hidden, KC = NM / 2;
+    const int SD = d.domain == BSDFD_DOMAIN_DISK ? 2 : 3;
+    const int IN = SD + 1 + 2 + 4 * PE_BANDS;
+    const int BIN = 2 + 4 * BASE_PE_BANDS;
+    auto align16 = [](int x) { return (x + 15) & ~15; };
+    int off = 0;
+    L.win = off; off += NM * 64 * 4;
+    L.wc = off; off += NM * PE_SLABS * 64 * 4;
+    if (prec == BSDFD_PREC_F32) {
+        L.wh = off; off += (NH - 1) * NM * NM * 64 * 16;
+        L.wh_lo = L.wh;
+        L.wo = off; off += NM * 64 * 16;
+    } else {
+        L.wh = off; off += (NH - 1) * NM * KC * 64 * 16;
+        L.wh_lo = off;
+        if (prec == BSDFD_PREC_SPLIT3) off += (NH - 1) * NM * KC * 64 * 16;
+        L.wo = off; off += KC * 64 * 16;
+    }
+    L.bw1 = off; off += (BASE_PE_BANDS + 1) * 64 * 4;
+    L.bb1 = off; off += 64 * 16;
+    L.bw2 = off; off += 64 * 16;
+    L.bb2 = off; off += 16;
+    L.total = align16(off);
+    std::vector<char> img(L.total, 0);
+    auto F = [&](int o) { return reinterpret_cast<float*>(img.data() + o); };
+    auto H = [&](int o) { return reinterpret_cast<uint16_t*>(img.data() + o); };
+
+    // PE entry (band b, fn f, dim dd) sits at PE index 2 + 4b + 2f + dd (model.py:26-57)
+    for (int l = 0; l < 64; ++l) {
+        const int g = l >> 4, i = l & 15;
+        for (int m = 0; m < NM; ++m) {
+            const int unit = 16 * m + i;
+            // state part: k = g -> disk [x0, x1, alpha, 0]; spherical [theta, sin, cos, alpha]
+            F(L.win)[m * 64 + l] = (g < SD + 1) ? d.w_in[unit * IN + g] : 0.0f;
+            for (int s = 0; s < PE_BANDS; ++s)
+                F(L.wc)[(m * PE_SLABS + s) * 64 + l] = d.w_in[unit * IN + SD + 1 + 2 + 4 * s + 2 * (g >> 1) + (g & 1)];
+            F(L.wc)[(m * PE_SLABS + PE_BANDS) * 64 + l] = g < 2 ? d.w_in[unit * IN + SD + 1 + g] : 0.0f;
+        }
+        // base net
+        for (int s = 0; s < BASE_PE_BANDS; ++s)
+            F(L.bw1)[s * 64 + l] = d.base_w1[i * BIN + 2 + 4 * s + 2 * (g >> 1) + (g & 1)];
+        F(L.bw1)[BASE_PE_BANDS * 64 + l] = g < 2 ? d.base_w1[i * BIN + g] : 0.0f;
+        for (int r = 0; r < 4; ++r) {
+            F(L.bb1)[l * 4 + r] = d.base_b1[4 * g + r];
+            F(L.bw2)[l * 4 + r] = d.base_w2[(i & 3) * BASE_HIDDEN + 4 * g + r];
+        }
+    }
+    for (int r = 0; r < 4; ++r) F(L.bb2)[r] = d.base_b2[r];
+
+    if (prec == BSDFD_PREC_F32) {
+        for (int layer = 0; layer < NH - 1; ++layer)
+            for (int mo = 0; mo < NM; ++mo)
+                for (int m = 0; m < NM; ++m)
+                    for (int l = 0; l < 64; ++l)
+                        for (int r = 0; r < 4; ++r)
+                            F(L.wh)[((((size_t)layer * NM + mo) * NM + m) * 64 + l) * 4 + r] =
+                                d.w_hidden[((size_t)layer * W + 16 * mo + (l & 15)) * W + 16 * m + 4 * (l >> 4) + r];
+        for (int m = 0; m < NM; ++m)
+            for (int l = 0; l < 64; ++l)
+                for (int r = 0; r < 4; ++r) {
+                    const int o = (l & 15) & 3;
+                    F(L.wo)[(m * 64 + l) * 4 + r] = o < 2 ? d.w_out[o * W + 16 * m + 4 * (l >> 4) + r] : 0.0f;
+                }
+    } else {
+        for (int layer = 0; layer < NH - 1; ++layer)
+            for (int mo = 0; mo < NM; ++mo)
+                for (int kc = 0; kc < KC; ++kc)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = 16 * (2 * kc + (j >> 2)) + 4 * (l >> 4) + (j & 3);
+                            const float w = d.w_hidden[((size_t)layer * W + 16 * mo + (l & 15)) * W + k];
+                            const size_t idx = ((((size_t)layer * NM + mo) * KC + kc) * 64 + l) * 8 + j;
+                            const float hi = f16_round(w);
+                            H(L.wh)[idx] = f32_to_f16_bits(w);
+                            if (prec == BSDFD_PREC_SPLIT3) H(L.wh_lo)[idx] = f32_to_f16_bits((w - hi) * LO_SCALE);
+                        }
+        for (int kc = 0; kc < KC; ++kc)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * (2 * kc + (j >> 2)) + 4 * (l >> 4) + (j & 3);
+                    const int o = (l & 15) & 3;
+                    const float w = d.w_out[(o & 1) * W + k];
+                    float val;
+                    if (o < 2) val = w;
+                    else val = (prec == BSDFD_PREC_SPLIT3) ? (w - f16_round(w)) * LO_SCALE : 0.0f;
+                    H(L.wo)[((size_t)kc * 64 + l) * 8 + j] = f32_to_f16_bits(val);
+                }
+    }
+    return img;
+}
+
+template <int DOMAIN, int NM, int PREC>
+hipError_t launch_jac(bool jac, dim3 grid, dim3 block, size_t lds, hipStream_t s, const KParams& kp) {
+    if (jac) {
+        auto k = flow_kernel<DOMAIN, NM, PREC, true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds, s, kp);
+    } else {
+        auto k = flow_kernel<DOMAIN, NM, PREC, false>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, grid, block, lds, s, kp);
+    }
+    return hipGetLastError();
+}
+
+template <int DOMAIN, int NM>
+hipError_t launch_prec(int prec, bool jac, dim3 grid, dim3 block, size_t lds, hipStream_t s, const KParams& kp) {
+    switch (prec) {
+        case BSDFD_PREC_F32: return launch_jac<DOMAIN, NM, BSDFD_PREC_F32>(jac, grid, block, lds, s, kp);
+        case BSDFD_PREC_F16: return launch_jac<DOMAIN, NM, BSDFD_PREC_F16>(jac, grid, block, lds, s, kp);
+        default: return launch_jac<DOMAIN, NM, BSDFD_PREC_SPLIT3>(jac, grid, block, lds, s, kp);
+    }
+}
+
+int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, uint64_t seed, uint64_t offset,
+        int64_t N, int T, float* out_x, float* out_pdf, void* stream) {
+    if (!h) return fail(BSDFD_EINVAL, "null handle");
+    if (N < 0) return fail(BSDFD_EINVAL, "N must be >= 0");
+    if (T < 1 || T > 4096) return fail(BSDFD_EINVAL, "T must be in [1, 4096]");
+    if (N == 0) return BSDFD_OK;
+    if (!in_a) return fail(BSDFD_EINVAL, "null input pointer");
+    if (op == OP_PDF && !in_b) return fail(BSDFD_EINVAL, "pdf needs the outgoing directions");
+    if (op == OP_SAMPLES_ONLY && !in_b) return fail(BSDFD_EINVAL, "flow_samples_only needs x0");
+    if (op != OP_PDF && !out_x) return fail(BSDFD_EINVAL, "null output pointer");
+    if (op != OP_SAMPLES_ONLY && !out_pdf) return fail(BSDFD_EINVAL, "null pdf output pointer");
+    if (io == IO_PLUGIN_FULLSPHERE && h->domain != BSDFD_DOMAIN_SPHERICAL)
+        return fail(BSDFD_EINVAL, "the full-sphere plugin variant needs a spherical-domain handle");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != h->device) return fail(BSDFD_EINVAL, "handle was created on device " + std::to_string(h->device) +
+                                                        " but device " + std::to_string(dev) + " is current");
+    KParams kp;
+    kp.img = h->d_img; kp.L = h->L;
+    kp.in_a = in_a; kp.in_b = in_b; kp.out_x = out_x; kp.out_pdf = out_pdf;
+    kp.N = N; kp.T = T; kp.n_hidden = h->n_hidden; kp.op = op; kp.io = io; kp.seed = seed; kp.offset = offset;
+
+    const int NM = h->width / 16;
+    const int threads = NM == 2 ? 256 : 512;
+    const int waves = threads / 64;
+    const long long ntiles = (N + 15) / 16;
+    const long long want = (ntiles + waves - 1) / waves;
+    // LDS-limited residency: 160 KiB per CU
+    int per_cu = (int)(160 * 1024 / (h->L.total + 256));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu * waves > 32) per_cu = 32 / waves;
+    if (per_cu < 1) per_cu = 1;
+    const long long cap = (long long)h->num_cu * per_cu;
+    dim3 grid((unsigned)(want < cap ? want : cap)), block(threads);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool jac = op != OP_SAMPLES_ONLY;
+    if (h->profiling) HIP_TRY(hipEventRecord(h->ev0, s));
+    hipError_t e;
+    if (h->domain == BSDFD_DOMAIN_DISK)
+        e = NM == 2 ? launch_prec<BSDFD_DOMAIN_DISK, 2>(h->precision, jac, grid, block, h->L.total, s, kp)
+                    : launch_prec<BSDFD_DOMAIN_DISK, 4>(h->precision, jac, grid, block, h->L.total, s, kp);
+    else
+        e = NM == 2 ? launch_prec<BSDFD_DOMAIN_SPHERICAL, 2>(h->precision, jac, grid, block, h->L.total, s, kp)
+                    : launch_prec<BSDFD_DOMAIN_SPHERICAL, 4>(h->precision, jac, grid, block, h->L.total, s, kp);
+    if (e != hipSuccess) return fail(BSDFD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    if (h->profiling) {
+        HIP_TRY(hipEventRecord(h->ev1, s));
+        h->ev_valid = true;
+    }
+    return BSDFD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
+    if (!d || !out) return fail(BSDFD_EINVAL, "null argument");
+    *out = nullptr;
+    if (d->domain != BSDFD_DOMAIN_DISK && d->domain != BSDFD_DOMAIN_SPHERICAL)
+        return fail(BSDFD_EINVAL, "domain must be BSDFD_DOMAIN_DISK or BSDFD_DOMAIN_SPHERICAL");
+    if (d->width != 32 && d->width != 64) return fail(BSDFD_EINVAL, "width must be 32 or 64");
+    if (d->n_hidden < 1 || d->n_hidden > 16) return fail(BSDFD_EINVAL, "n_hidden must be in [1, 16]");
+    if (d->pe_bands != PE_BANDS) return fail(BSDFD_EINVAL, "pe_bands must be 5 (the reference's velocity nets)");
+    if (d->base_pe_bands != BASE_PE_BANDS || d->base_hidden != BASE_HIDDEN)
+        return fail(BSDFD_EINVAL, "base net must be PE_3 -> 16 -> 4 (the reference's pretrain nets)");
+    if (!d->w_in || !d->w_out || !d->base_w1 || !d->base_b1 || !d->base_w2 || !d->base_b2 ||
+        (d->n_hidden > 1 && !d->w_hidden))
+        return fail(BSDFD_EINVAL, "null weight pointer");
+    int prec = d->precision == BSDFD_PREC_DEFAULT ? BSDFD_PREC_SPLIT3 : d->precision;
+    if (prec != BSDFD_PREC_F32 && prec != BSDFD_PREC_SPLIT3 && prec != BSDFD_PREC_F16)
+        return fail(BSDFD_EINVAL, "unknown precision");
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(BSDFD_EINVAL, std::string("bsdfd is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
+    bsdfd_ctx* h = new bsdfd_ctx();
+    h->domain = d->domain; h->width = d->width; h->n_hidden = d->n_hidden; h->precision = prec;
+    h->state_dim = d->domain == BSDFD_DOMAIN_DISK ? 2 : 3;
+    h->in_dim = h->state_dim + 1 + 2 + 4 * PE_BANDS;
+    h->device = dev; h->num_cu = prop.multiProcessorCount;
+    h->profiling = false; h->ev_valid = false; h->d_img = nullptr;
+    std::vector<char> img = build_image(*d, prec, h->L);
+    if (h->L.total > 160 * 1024 - 512) {
+        delete h;
+        return fail(BSDFD_EINVAL, "weight image does not fit the 160 KiB LDS; use fewer layers or BSDFD_PREC_F16");
+    }
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_img), img.size());
+    if (e == hipSuccess) e = hipMemcpy(h->d_img, img.data(), img.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e != hipSuccess) {
+        if (h->d_img) hipFree(h->d_img);
+        delete h;
+        return fail(BSDFD_EHIP, std::string("create: ") + hipGetErrorString(e));
+    }
+    *out = h;
+    return BSDFD_OK;
+}
+
+int bsdfd_create_from_file(const char* path, int32_t precision, bsdfd_handle* out) {
+    if (!path || !out) return fail(BSDFD_EINVAL, "null argument");
+    *out = nullptr;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return fail(BSDFD_EIO, std::string("cannot open ") + path);
+    std::vector<char> raw;
+    char buf[65536];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) raw.insert(raw.end(), buf, buf + n);
+    std::fclose(f);
+    if (raw.size() < 104 || std::memcmp(raw.data(), "BSDFWT01", 8) != 0)
+        return fail(BSDFD_EIO, std::string(path) + ": not a BSDFWT01 weight file");
+    int32_t hdr[8];
+    std::memcpy(hdr, raw.data() + 72, sizeof hdr);
+    bsdfd_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.domain = hdr[0]; d.width = hdr[1]; d.n_hidden = hdr[2]; d.pe_bands = hdr[3];
+    d.base_hidden = hdr[4]; d.base_pe_bands = hdr[5]; d.precision = precision;
+    if (d.width <= 0 || d.width > 4096 || d.n_hidden < 1 || d.n_hidden > 64 || d.pe_bands < 0 || d.pe_bands > 64 ||
+        d.base_hidden <= 0 || d.base_hidden > 4096 || d.base_pe_bands < 0 || d.base_pe_bands > 64)
+        return fail(BSDFD_EIO, std::string(path) + ": implausible header");
+    const int sd = d.domain == BSDFD_DOMAIN_DISK ? 2 : 3;
+    if (hdr[6] != sd) return fail(BSDFD_EIO, std::string(path) + ": state_dim inconsistent with domain");
+    const size_t in_dim = sd + 1 + 2 + 4 * d.pe_bands, bin = 2 + 4 * d.base_pe_bands;
+    const size_t cnt[7] = {(size_t)d.width * in_dim, (size_t)(d.n_hidden - 1) * d.width * d.width, (size_t)2 * d.width,
+                           (size_t)d.base_hidden * bin, (size_t)d.base_hidden, (size_t)4 * d.base_hidden, 4};
+    size_t total = 0;
+    for (size_t c : cnt) total += c;
+    if (raw.size() != 104 + 4 * total) return fail(BSDFD_EIO, std::string(path) + ": payload size mismatch");
+    const float* p = reinterpret_cast<const float*>(raw.data() + 104);
+    d.w_in = p; p += cnt[0];
+    d.w_hidden = p; p += cnt[1];
+    d.w_out = p; p += cnt[2];
+    d.base_w1 = p; p += cnt[3];
+    d.base_b1 = p; p += cnt[4];
+    d.base_w2 = p; p += cnt[5];
+    d.base_b2 = p;
+    return bsdfd_create(&d, out);
+}
+
+void bsdfd_destroy(bsdfd_handle h) {
+    if (!h) return;
+    if (h->d_img) (void)hipFree(h->d_img);
+    (void)hipEventDestroy(h->ev0);
+    (void)hipEventDestroy(h->ev1);
+    delete h;
+}
+
+int bsdfd_get_info(bsdfd_handle h, int32_t* domain, int32_t* width, int32_t* n_hidden, int32_t* precision) {
+    if (!h) return fail(BSDFD_EINVAL, "null handle");
+    if (domain) *domain = h->domain;
+    if (width) *width = h->width;
+    if (n_hidden) *n_hidden = h->n_hidden;
+    if (precision) *precision = h->precision;
+    return BSDFD_OK;
+}
+
+int64_t bsdfd_flops_per_query(bsdfd_handle h, int32_t T) {
+    if (!h) return -1;
+    const int64_t w = h->width, nh = h->n_hidden;
+    const int64_t fwd = (int64_t)h->in_dim * w + (nh - 1) * w * w + 2 * w;
+    int64_t tang = 2 * ((nh - 1) * w * w + 2 * w);
+    if (h->state_dim == 3) tang += 2 * w;
+    const int64_t base = 2 * ((2 + 4 * BASE_PE_BANDS) * BASE_HIDDEN + 4 * BASE_HIDDEN);
+    return (int64_t)T * 2 * (fwd + tang) + base;
+}
+
+int bsdfd_network_sampling(bsdfd_handle h, const float* omega_i, const float* x0, uint64_t seed, uint64_t offset,
+                           int64_t N, int32_t T, float* x_out, float* pdf_out, void* stream) {
+    return run(h, OP_SAMPLE, IO_OPERATOR, omega_i, x0, seed, offset, N, T, x_out, pdf_out, stream);
+}
+
+int bsdfd_network_pdf(bsdfd_handle h, const float* omega_o, const float* omega_i, int64_t N, int32_t T,
+                      float* pdf_out, void* stream) {
+    return run(h, OP_PDF, IO_OPERATOR, omega_i, omega_o, 0, 0, N, T, nullptr, pdf_out, stream);
+}
+
+int bsdfd_plugin_sample(bsdfd_handle h, int32_t variant, const float* wi, const float* x0, uint64_t seed,
+                        uint64_t offset, int64_t N, int32_t T, float* wo, float* pdf_sa, void* stream) {
+    if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
+        return fail(BSDFD_EINVAL, "unknown plugin variant");
+    return run(h, OP_SAMPLE, variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, x0, seed, offset,
+               N, T, wo, pdf_sa, stream);
+}
+
+int bsdfd_plugin_pdf(bsdfd_handle h, int32_t variant, const float* wi, const float* wo, int64_t N, int32_t T,
+                     float* pdf_sa, void* stream) {
+    if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
+        return fail(BSDFD_EINVAL, "unknown plugin variant");
+    return run(h, OP_PDF, variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, wo, 0, 0, N, T,
+               nullptr, pdf_sa, stream);
+}
+
+int bsdfd_flow_samples_only(bsdfd_handle h, const float* omega_i, const float* x0, int64_t N, int32_t T,
+                            float* x_out, void* stream) {
+    return run(h, OP_SAMPLES_ONLY, IO_OPERATOR, omega_i, x0, 0, 0, N, T, x_out, nullptr, stream);
+}
+
+int bsdfd_set_profiling(bsdfd_handle h, int32_t enable) {
+    if (!h) return fail(BSDFD_EINVAL, "null handle");
+    h->profiling = enable != 0;
+    h->ev_valid = false;
+    return BSDFD_OK;
+}
+
+float bsdfd_last_kernel_ms(bsdfd_handle h) {
+    if (!h || !h->profiling || !h->ev_valid) return -1.0f;
+    if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+const char* bsdfd_last_error(void) { return g_err.c_str(); }
+const char* bsdfd_version(void) { return "bsdfd 0.1 (gfx950)"; }
+
+}  // extern "C"

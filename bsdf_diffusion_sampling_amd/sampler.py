@@ -1,0 +1,151 @@
+"""``FlowSampler`` — packed device-side handle of one (material, domain) flow sampler.
+
+Thin host object over the C ABI (include/bsdfd.h).  PyTorch is used only for device
+memory and the current HIP stream; all arithmetic happens in the HIP kernels of
+csrc/bsdfd.hip.  Checks mirror the contiguity/dtype/device checks of the reference's
+only native binding (tiny-cuda-nn/bindings/torch/tinycudann/bindings.cpp:54-73).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import weights as W
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class FlowSampler:
+    def __init__(self, fw: "W.FlowWeights | str", precision: str = "default", device: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("FlowSampler needs an MI355X (torch.cuda is unavailable); there is no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        if isinstance(fw, str):
+            fw = W.load(fw)
+        self.weights = fw.validate()
+        self.domain = fw.domain
+        L = _lib.lib()
+        d = _lib.Desc()
+        d.domain, d.width, d.n_hidden, d.pe_bands = fw.domain, fw.width, fw.n_hidden, fw.pe_bands
+        d.base_hidden, d.base_pe_bands = fw.base_hidden, fw.base_pe_bands
+        d.precision = _lib.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+        keep = []
+        for name in ("w_in", "w_hidden", "w_out", "base_w1", "base_b1", "base_w2", "base_b2"):
+            a = np.ascontiguousarray(getattr(fw, name), dtype=np.float32)
+            keep.append(a)
+            setattr(d, name, a.ctypes.data_as(C.POINTER(C.c_float)))
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.bsdfd_create(C.byref(d), C.byref(h)))
+        self._h = h
+        self._L = L
+        p = C.c_int32()
+        _lib.check(L.bsdfd_get_info(h, None, None, None, C.byref(p)))
+        self.precision = {v: k for k, v in _lib.PRECISIONS.items()}[p.value]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.bsdfd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------
+    def _chk(self, t: Optional[torch.Tensor], cols: int, name: str, n: Optional[int] = None):
+        if t is None:
+            return None
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise RuntimeError(f"{name} must be a CUDA (HIP) tensor")
+        if t.device != self.device:
+            raise RuntimeError(f"{name} is on {t.device}, the sampler on {self.device}")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+        if t.dim() != 2 or t.shape[1] != cols:
+            raise RuntimeError(f"{name} must have shape [N, {cols}], got {tuple(t.shape)}")
+        if n is not None and t.shape[0] != n:
+            raise RuntimeError(f"{name} has {t.shape[0]} rows, expected {n}")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{name} must be contiguous")
+        return t
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def flops_per_query(self, T: int) -> int:
+        return int(self._L.bsdfd_flops_per_query(self._h, T))
+
+    def set_profiling(self, on: bool):
+        _lib.check(self._L.bsdfd_set_profiling(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self) -> float:
+        return float(self._L.bsdfd_last_kernel_ms(self._h))
+
+    # ---- operator level (rendering/utils/mlp_brdf_sampling.py) -------
+    def network_sampling(self, omega_i, x0=None, T: int = 4, seed: int = 0, offset: int = 0
+                         ) -> Tuple[torch.Tensor, torch.Tensor]:
+        omega_i = self._chk(omega_i, 2, "omega_i")
+        n = omega_i.shape[0]
+        x0 = self._chk(x0, 2, "x0", n)
+        x = torch.empty((n, 2), dtype=torch.float32, device=self.device)
+        pdf = torch.empty((n,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.bsdfd_network_sampling(self._h, _ptr(omega_i), _ptr(x0), seed, offset, n, T,
+                                                      _ptr(x), _ptr(pdf), self._stream()))
+        return x, pdf
+
+    def network_pdf(self, omega_o, omega_i, T: int = 4) -> torch.Tensor:
+        omega_i = self._chk(omega_i, 2, "omega_i")
+        n = omega_i.shape[0]
+        omega_o = self._chk(omega_o, 2, "omega_o", n)
+        pdf = torch.empty((n,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.bsdfd_network_pdf(self._h, _ptr(omega_o), _ptr(omega_i), n, T, _ptr(pdf),
+                                                 self._stream()))
+        return pdf
+
+    def flow_samples_only(self, omega_i, x0, T: int) -> torch.Tensor:
+        omega_i = self._chk(omega_i, 2, "omega_i")
+        n = omega_i.shape[0]
+        x0 = self._chk(x0, 2, "x0", n)
+        x = torch.empty((n, 2), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.bsdfd_flow_samples_only(self._h, _ptr(omega_i), _ptr(x0), n, T, _ptr(x),
+                                                       self._stream()))
+        return x
+
+    # ---- plugin level (tensor core of MyBSDF.sample / MyBSDF.pdf) ----
+    def plugin_sample(self, wi, x0=None, T: int = 4, variant: int = _lib.PLUGIN_MEASURED, seed: int = 0,
+                      offset: int = 0, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        wi = self._chk(wi, 3, "wi")
+        n = wi.shape[0]
+        x0 = self._chk(x0, 2, "x0", n)
+        if out is None:
+            wo = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+            pdf = torch.empty((n,), dtype=torch.float32, device=self.device)
+        else:
+            wo, pdf = self._chk(out[0], 3, "out wo", n), out[1]
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.bsdfd_plugin_sample(self._h, variant, _ptr(wi), _ptr(x0), seed, offset, n, T,
+                                                   _ptr(wo), _ptr(pdf), self._stream()))
+        return wo, pdf
+
+    def plugin_pdf(self, wi, wo, T: int = 4, variant: int = _lib.PLUGIN_MEASURED,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        wi = self._chk(wi, 3, "wi")
+        n = wi.shape[0]
+        wo = self._chk(wo, 3, "wo", n)
+        pdf = torch.empty((n,), dtype=torch.float32, device=self.device) if out is None else out
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.bsdfd_plugin_pdf(self._h, variant, _ptr(wi), _ptr(wo), n, T, _ptr(pdf),
+                                                self._stream()))
+        return pdf

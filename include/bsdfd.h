@@ -1,0 +1,138 @@
+/*
+ * bsdfd.h — C ABI of the MI355X-native neural-BSDF flow sampler ("bsdfd").
+ *
+ * This is the drop-in boundary for the ONE hot path of fzy28/BSDF_diffusion_sampling:
+ * the per-query rectified-flow sampler and its change-of-variables PDF behind the
+ * Mitsuba plugin methods sample()/pdf().  Plain pointers and sizes only — no torch
+ * types.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference repo root).
+ *
+ * Conventions (modelled on how the reference binds its only native library,
+ * tiny-cuda-nn/bindings/torch/tinycudann/bindings.cpp:79-110):
+ *   - all data pointers are DEVICE pointers to contiguous row-major fp32, caller-owned;
+ *   - no allocation inside sample/pdf calls; any N >= 0 (ragged tail handled in-kernel);
+ *   - work is enqueued on the HIP stream the caller passes (NULL = default stream)
+ *     and the call returns without synchronising;
+ *   - return value 0 = ok, otherwise a BSDFD_E* code; bsdfd_last_error() returns a
+ *     thread-local message (the Python host raises RuntimeError with it);
+ *   - a handle is immutable after create and bound to the device current at create;
+ *     calls are re-entrant across streams.
+ */
+#ifndef BSDFD_H
+#define BSDFD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSDFD_OK 0
+#define BSDFD_EINVAL 1   /* bad argument / unsupported architecture */
+#define BSDFD_EHIP 2     /* a HIP runtime call failed */
+#define BSDFD_EIO 3      /* weight file unreadable / malformed */
+
+#define BSDFD_DOMAIN_DISK 0       /* state = 2-D point on the unit disk          */
+#define BSDFD_DOMAIN_SPHERICAL 1  /* state = (theta, phi); net input [theta, sin phi, cos phi] */
+
+/* Arithmetic of the dense layer contractions (activations, Jacobian determinant,
+ * base density and warps are always fp32 VALU). */
+#define BSDFD_PREC_DEFAULT 0  /* = BSDFD_PREC_SPLIT3 */
+#define BSDFD_PREC_F32 1      /* v_mfma_f32_16x16x4_f32: exact fp32 FMA chains (validation mode) */
+#define BSDFD_PREC_SPLIT3 2   /* fp16 MFMA, operands split hi+lo, 3 products, fp32 accumulate (<=1e-4 parity) */
+#define BSDFD_PREC_F16 3      /* single fp16 MFMA pass (tcnn-class 1e-2 tolerance; reflow teacher sampling) */
+
+/* Plugin post-processing variants (which MyBSDF the call mirrors). */
+#define BSDFD_PLUGIN_MEASURED 0    /* rendering/brdf_measured_{disk,spherical}.py */
+#define BSDFD_PLUGIN_FULLSPHERE 1  /* rendering/bsdf_myresult.py (spherical only) */
+
+typedef struct bsdfd_ctx* bsdfd_handle;
+
+/* Host pointers to fp32 row-major [out, in] matrices exactly as nn.Linear.weight
+ * stores them (reference checkpoints: rendering/checkpoints_new/.../brdf_rectify_network*.pth
+ * and brdf_pretrain_network*.pth, loaded at rendering/brdf_measured_disk.py:43-51).
+ * The library copies and re-packs them; the caller may free them after create. */
+typedef struct bsdfd_desc {
+    int32_t domain;         /* BSDFD_DOMAIN_*                                            */
+    int32_t width;          /* hidden width of the velocity net: 32 or 64                */
+    int32_t n_hidden;       /* hidden layers: 3 (disk), 4 (spherical), 6 (64-wide teacher) */
+    int32_t pe_bands;       /* positional-encoding bands of the velocity net (5)         */
+    int32_t base_hidden;    /* hidden width of the base-density net (16)                 */
+    int32_t base_pe_bands;  /* positional-encoding bands of the base net (3)             */
+    int32_t precision;      /* BSDFD_PREC_*                                              */
+    int32_t reserved;
+    const float* w_in;      /* [width, state_dim + 1 + 2 + 4*pe_bands], cols [state|alpha|PE(omega_i)] */
+    const float* w_hidden;  /* [n_hidden-1, width, width]                                */
+    const float* w_out;     /* [2, width]                                                */
+    const float* base_w1;   /* [base_hidden, 2 + 4*base_pe_bands]                        */
+    const float* base_b1;   /* [base_hidden]                                             */
+    const float* base_w2;   /* [4, base_hidden]                                          */
+    const float* base_b2;   /* [4]                                                       */
+} bsdfd_desc;
+
+/* Replaces MyBSDF.__init__'s network construction + load_state_dict
+ * (rendering/brdf_measured_disk.py:43-51, brdf_measured_spherical.py:53-59,
+ * bsdf_myresult.py:49-54). */
+int bsdfd_create(const bsdfd_desc* desc, bsdfd_handle* out);
+
+/* Same, from a neutral .bsdfw file (format: bsdf_diffusion_sampling_amd/weights.py);
+ * replaces torch.load of the pickle checkpoints. precision = BSDFD_PREC_*. */
+int bsdfd_create_from_file(const char* path, int32_t precision, bsdfd_handle* out);
+
+void bsdfd_destroy(bsdfd_handle h);
+
+/* Introspection (host side mirrors / bench): domain, width, n_hidden, precision in
+ * effect; algorithmic flop per query for T Euler steps. */
+int bsdfd_get_info(bsdfd_handle h, int32_t* domain, int32_t* width, int32_t* n_hidden,
+                   int32_t* precision);
+int64_t bsdfd_flops_per_query(bsdfd_handle h, int32_t T);
+
+/* network_sampling_disk / network_sampling_spherical
+ * (rendering/utils/mlp_brdf_sampling.py:17-51, :106-140).
+ *   omega_i [N,2]  condition: disk coords of wi, or (theta_i, phi_i)
+ *   x0      [N,2]  base draw, or NULL: drawn in-kernel from D_base with a Philox4x32-10
+ *                  stream keyed (seed, offset + query index) — statistically, not
+ *                  bit-wise, equal to torch's RNG
+ *   x_out   [N,2]  flowed sample;  pdf_out [N]  p0(x0) * prod 1/det(I + J/T), signed. */
+int bsdfd_network_sampling(bsdfd_handle h, const float* omega_i, const float* x0, uint64_t seed,
+                           uint64_t offset, int64_t N, int32_t T, float* x_out, float* pdf_out,
+                           void* hip_stream);
+
+/* network_pdf_disk / network_pdf_spherical (mlp_brdf_sampling.py:69-103, :144-181). */
+int bsdfd_network_pdf(bsdfd_handle h, const float* omega_o, const float* omega_i, int64_t N,
+                      int32_t T, float* pdf_out, void* hip_stream);
+
+/* Tensor core of MyBSDF.sample with the domain warp and guards fused
+ * (rendering/brdf_measured_disk.py:59-82; brdf_measured_spherical.py:69-91;
+ *  bsdf_myresult.py:59-84 when variant = BSDFD_PLUGIN_FULLSPHERE):
+ *   wi [N,3] unit vectors in the local frame -> wo [N,3], pdf_sa [N] (solid-angle pdf).
+ * The measured.eval()-dependent firefly rule (:97-100) is NOT applied here. */
+int bsdfd_plugin_sample(bsdfd_handle h, int32_t variant, const float* wi, const float* x0,
+                        uint64_t seed, uint64_t offset, int64_t N, int32_t T, float* wo,
+                        float* pdf_sa, void* hip_stream);
+
+/* Tensor core of MyBSDF.pdf (rendering/brdf_measured_disk.py:112-124;
+ * brdf_measured_spherical.py:122-137; bsdf_myresult.py:115-133). */
+int bsdfd_plugin_pdf(bsdfd_handle h, int32_t variant, const float* wi, const float* wo, int64_t N,
+                     int32_t T, float* pdf_sa, void* hip_stream);
+
+/* Reflow teacher sampling without the Jacobian: x <- x + v(x, t/T | omega_i)/T for T steps
+ * (learning_repo_cleanup/spherical_domain_sampling.py:147-166, disk_domain_sampling.py:93-110 —
+ * the reference's only tiny-cuda-nn call site). x0 [N,2] in, x_out [N,2] out. */
+int bsdfd_flow_samples_only(bsdfd_handle h, const float* omega_i, const float* x0, int64_t N,
+                            int32_t T, float* x_out, void* hip_stream);
+
+/* Timing of the most recent kernel launched through this handle on `hip_stream`:
+ * the library brackets every launch with a pair of HIP events on the launch stream when
+ * profiling is enabled. Returns the kernel's duration in milliseconds (synchronises on the
+ * stop event), or a negative value if profiling is disabled / nothing was launched. */
+int bsdfd_set_profiling(bsdfd_handle h, int32_t enable);
+float bsdfd_last_kernel_ms(bsdfd_handle h);
+
+const char* bsdfd_last_error(void);
+const char* bsdfd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSDFD_H */
