@@ -24,7 +24,7 @@ EXPORTS = (
     "bsdfd_create", "bsdfd_create_from_file", "bsdfd_destroy", "bsdfd_get_info",
     "bsdfd_flops_per_query", "bsdfd_network_sampling", "bsdfd_network_pdf",
     "bsdfd_plugin_sample", "bsdfd_plugin_pdf", "bsdfd_flow_samples_only",
-    "bsdfd_set_profiling", "bsdfd_last_kernel_ms", "bsdfd_last_error", "bsdfd_version",
+    "bsdfd_set_profiling", "bsdfd_profile_read", "bsdfd_last_kernel_ms", "bsdfd_last_error", "bsdfd_version",
 )
 
 
@@ -75,6 +75,7 @@ def lib():
     L.bsdfd_plugin_pdf.argtypes = [vp, i32, fp, fp, i64, i32, fp, vp]
     L.bsdfd_flow_samples_only.argtypes = [vp, fp, fp, i64, i32, fp, vp]
     L.bsdfd_set_profiling.argtypes = [vp, i32]
+    L.bsdfd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]
     L.bsdfd_last_kernel_ms.argtypes = [vp]
     L.bsdfd_last_kernel_ms.restype = C.c_float
     L.bsdfd_last_error.restype = C.c_char_p

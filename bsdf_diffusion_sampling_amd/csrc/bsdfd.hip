@@ -41,13 +41,16 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int PE_BANDS = 5;       // rendering/brdf_measured_disk.py:43 (POSITIONAL_ENCODING_BASIS_NUM=5)
 constexpr int BASE_PE_BANDS = 3;  // :49
 constexpr int BASE_HIDDEN = 16;
 constexpr int PE_SLABS = PE_BANDS + 1;  // K=4 slabs: one per band (sin/cos x 2 dims) + the raw (y0,y1) slab
-constexpr float LO_SCALE = 2048.0f;     // lo halves are stored x2^11 so they stay in fp16's normal range
-constexpr float LO_INV = 1.0f / 2048.0f;
+// Split-fp16 operands: x = hi + lo with hi = x truncated to fp16's 11 significant bits (one v_and)
+// and lo = fp16(x - hi).  lo may be an fp16 subnormal; the gfx950 MFMA honours fp16 subnormal
+// inputs (measured: tools/ubench/denorm.hip), so no rescaling is needed and all three products
+// hi*hi + hi*lo + lo*hi accumulate into ONE fp32 accumulator.
 
 enum { OP_SAMPLE = 0, OP_PDF = 1, OP_SAMPLES_ONLY = 2 };
 enum { IO_OPERATOR = 0, IO_PLUGIN = 1, IO_PLUGIN_FULLSPHERE = 2 };
@@ -82,13 +85,38 @@ __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
 }
 
 // SiLU and its derivative from one sigmoid: h = z*s, g = s*(1 + z*(1-s)) = s + h*(1-s).
+// v_exp_f32 / v_rcp_f32 are 1-ulp hardware transcendentals (quarter rate: the two of them are
+// 16 of the ~26 VALU cycles a hidden unit costs).
+__device__ __forceinline__ float sigmoid_fast(float z) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896340736f));
+}
 __device__ __forceinline__ void silu_grad(float z, float& h, float& g) {
-    const float e = __expf(-z);
-    const float s = __frcp_rn(1.0f + e);
+    const float s = sigmoid_fast(z);
     h = z * s;
     g = fmaf(h, 1.0f - s, s);
 }
-__device__ __forceinline__ float silu(float z) { return z * __frcp_rn(1.0f + __expf(-z)); }
+__device__ __forceinline__ float silu(float z) { return z * sigmoid_fast(z); }
+
+// hi/lo split of an fp32 value into two fp16-representable fp32 values (see header comment)
+__device__ __forceinline__ float hi_part(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFFE000u); }
+
+union Frag {  // one MFMA B fragment: the lane's 8 K-values of a chunk
+    f16x8 v;
+    f16x2 p[4];
+};
+template <bool SPLIT>
+__device__ __forceinline__ void split_pack(const float (&x)[4], f16x2& h01, f16x2& h23, f16x2& l01, f16x2& l23) {
+    if (SPLIT) {
+        const float h0 = hi_part(x[0]), h1 = hi_part(x[1]), h2 = hi_part(x[2]), h3 = hi_part(x[3]);
+        h01 = (f16x2){(_Float16)h0, (_Float16)h1};
+        h23 = (f16x2){(_Float16)h2, (_Float16)h3};
+        l01 = (f16x2){(_Float16)(x[0] - h0), (_Float16)(x[1] - h1)};
+        l23 = (f16x2){(_Float16)(x[2] - h2), (_Float16)(x[3] - h3)};
+    } else {
+        h01 = (f16x2){(_Float16)x[0], (_Float16)x[1]};
+        h23 = (f16x2){(_Float16)x[2], (_Float16)x[3]};
+    }
+}
 
 __device__ __forceinline__ float sel4(int g, float a0, float a1, float a2, float a3) {
     return g == 0 ? a0 : (g == 1 ? a1 : (g == 2 ? a2 : a3));
@@ -414,75 +442,76 @@ __global__ __launch_bounds__(512) void flow_kernel(const KParams p) {
                         }
                     }
                 } else {
-                    // fp16 MFMA path: B fragments are the lane's own 8 values per K chunk, split
-                    // into hi = fp16(x) and lo = fp16((x - hi) * 2^11).
-                    f16x8 bh[KC], bl[KC], b0h[KC], b0l[KC], b1h[KC], b1l[KC];
+                    // fp16 MFMA path.  The lane's own 8 values per K chunk ARE the B fragment; each
+                    // is split into hi + lo (SPLIT3) and the three products share one accumulator.
+                    constexpr bool SPLIT = (PREC == BSDFD_PREC_SPLIT3);
+                    Frag bh[KC], bl[KC], b0h[KC], b0l[KC], b1h[KC], b1l[KC];
 #pragma unroll
                     for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float xv = h[2 * kc + (j >> 2)][j & 3];
-                            const _Float16 hv = (_Float16)xv;
-                            bh[kc][j] = hv;
-                            if (PREC == BSDFD_PREC_SPLIT3) bl[kc][j] = (_Float16)((xv - (float)hv) * LO_SCALE);
+                        for (int half = 0; half < 2; ++half) {
+                            const int m = 2 * kc + half;
+                            split_pack<SPLIT>(h[m], bh[kc].p[2 * half], bh[kc].p[2 * half + 1], bl[kc].p[2 * half],
+                                              bl[kc].p[2 * half + 1]);
                             if (JAC) {
-                                const float x0v = t0[2 * kc + (j >> 2)][j & 3], x1v = t1[2 * kc + (j >> 2)][j & 3];
-                                const _Float16 h0 = (_Float16)x0v, h1 = (_Float16)x1v;
-                                b0h[kc][j] = h0; b1h[kc][j] = h1;
-                                if (PREC == BSDFD_PREC_SPLIT3) {
-                                    b0l[kc][j] = (_Float16)((x0v - (float)h0) * LO_SCALE);
-                                    b1l[kc][j] = (_Float16)((x1v - (float)h1) * LO_SCALE);
-                                }
+                                split_pack<SPLIT>(t0[m], b0h[kc].p[2 * half], b0h[kc].p[2 * half + 1],
+                                                  b0l[kc].p[2 * half], b0l[kc].p[2 * half + 1]);
+                                split_pack<SPLIT>(t1[m], b1h[kc].p[2 * half], b1h[kc].p[2 * half + 1],
+                                                  b1l[kc].p[2 * half], b1l[kc].p[2 * half + 1]);
                             }
                         }
                     if (!last) {
                         const size_t lbase = (size_t)layer * NM * KC * 64 * 16;
+                        f32x4 a[NM], a0[NM], a1[NM];
 #pragma unroll
-                        for (int mo = 0; mo < NM; ++mo) {
-                            f32x4 a = zero4, a0 = zero4, a1 = zero4;     // hi*hi
-                            f32x4 ac = zero4, a0c = zero4, a1c = zero4;  // (hi*lo + lo*hi) * 2^11
+                        for (int mo = 0; mo < NM; ++mo) { a[mo] = zero4; a0[mo] = zero4; a1[mo] = zero4; }
 #pragma unroll
-                            for (int kc = 0; kc < KC; ++kc) {
+                        for (int kc = 0; kc < KC; ++kc) {
+                            f16x8 wh[NM], wl[NM];
+#pragma unroll
+                            for (int mo = 0; mo < NM; ++mo) {
                                 const size_t off = lbase + ((size_t)(mo * KC + kc) * 64 + lane) * 16;
-                                const f16x8 wh = *reinterpret_cast<const f16x8*>(Lwh + off);
-                                a = mfma16(wh, bh[kc], a);
-                                if (JAC) { a0 = mfma16(wh, b0h[kc], a0); a1 = mfma16(wh, b1h[kc], a1); }
-                                if (PREC == BSDFD_PREC_SPLIT3) {
-                                    const f16x8 wl = *reinterpret_cast<const f16x8*>(Lwh_lo + off);
-                                    ac = mfma16(wh, bl[kc], ac);
-                                    ac = mfma16(wl, bh[kc], ac);
-                                    if (JAC) {
-                                        a0c = mfma16(wh, b0l[kc], a0c); a0c = mfma16(wl, b0h[kc], a0c);
-                                        a1c = mfma16(wh, b1l[kc], a1c); a1c = mfma16(wl, b1h[kc], a1c);
-                                    }
+                                wh[mo] = *reinterpret_cast<const f16x8*>(Lwh + off);
+                                if (SPLIT) wl[mo] = *reinterpret_cast<const f16x8*>(Lwh_lo + off);
+                            }
+                            // term-major order: consecutive MFMAs hit different accumulators
+#pragma unroll
+                            for (int mo = 0; mo < NM; ++mo) {
+                                a[mo] = mfma16(wh[mo], bh[kc].v, a[mo]);
+                                if (JAC) { a0[mo] = mfma16(wh[mo], b0h[kc].v, a0[mo]); a1[mo] = mfma16(wh[mo], b1h[kc].v, a1[mo]); }
+                            }
+                            if (SPLIT) {
+#pragma unroll
+                                for (int mo = 0; mo < NM; ++mo) {
+                                    a[mo] = mfma16(wh[mo], bl[kc].v, a[mo]);
+                                    if (JAC) { a0[mo] = mfma16(wh[mo], b0l[kc].v, a0[mo]); a1[mo] = mfma16(wh[mo], b1l[kc].v, a1[mo]); }
+                                }
+#pragma unroll
+                                for (int mo = 0; mo < NM; ++mo) {
+                                    a[mo] = mfma16(wl[mo], bh[kc].v, a[mo]);
+                                    if (JAC) { a0[mo] = mfma16(wl[mo], b0h[kc].v, a0[mo]); a1[mo] = mfma16(wl[mo], b1h[kc].v, a1[mo]); }
                                 }
                             }
-                            if (PREC == BSDFD_PREC_SPLIT3) {
-                                a += ac * LO_INV; a0 += a0c * LO_INV; a1 += a1c * LO_INV;
-                            }
-                            z[mo] = a; zt0[mo] = a0; zt1[mo] = a1;
                         }
+#pragma unroll
+                        for (int mo = 0; mo < NM; ++mo) { z[mo] = a[mo]; zt0[mo] = a0[mo]; zt1[mo] = a1[mo]; }
                     } else {
-                        // output layer: A rows (i&3) = {Wout_hi[0], Wout_hi[1], Wout_lo[0], Wout_lo[1]}
-                        f32x4 e = zero4, e0 = zero4, e1 = zero4;     // A * hi
-                        f32x4 f = zero4, f0 = zero4, f1 = zero4;     // A * lo
+                        // output layer: A rows (i&3) = {Wout_hi[0], Wout_hi[1], Wout_lo[0], Wout_lo[1]}, so
+                        // e[0..1] = hi*hi + hi*lo and e[2..3] = lo*hi (+ lo*lo, ~2^-22): out = e[o] + e[o+2]
+                        f32x4 e = zero4, e0 = zero4, e1 = zero4;
 #pragma unroll
                         for (int kc = 0; kc < KC; ++kc) {
                             const f16x8 wo = *reinterpret_cast<const f16x8*>(Lwo + ((size_t)kc * 64 + lane) * 16);
-                            e = mfma16(wo, bh[kc], e);
-                            if (JAC) { e0 = mfma16(wo, b0h[kc], e0); e1 = mfma16(wo, b1h[kc], e1); }
-                            if (PREC == BSDFD_PREC_SPLIT3) {
-                                f = mfma16(wo, bl[kc], f);
-                                if (JAC) { f0 = mfma16(wo, b0l[kc], f0); f1 = mfma16(wo, b1l[kc], f1); }
+                            e = mfma16(wo, bh[kc].v, e);
+                            if (JAC) { e0 = mfma16(wo, b0h[kc].v, e0); e1 = mfma16(wo, b1h[kc].v, e1); }
+                            if (SPLIT) {
+                                e = mfma16(wo, bl[kc].v, e);
+                                if (JAC) { e0 = mfma16(wo, b0l[kc].v, e0); e1 = mfma16(wo, b1l[kc].v, e1); }
                             }
                         }
-                        if (PREC == BSDFD_PREC_SPLIT3) {
-                            v[0] = e[0] + (e[2] + f[0]) * LO_INV;   v[1] = e[1] + (e[3] + f[1]) * LO_INV;
-                            d0[0] = e0[0] + (e0[2] + f0[0]) * LO_INV; d0[1] = e0[1] + (e0[3] + f0[1]) * LO_INV;
-                            d1[0] = e1[0] + (e1[2] + f1[0]) * LO_INV; d1[1] = e1[1] + (e1[3] + f1[1]) * LO_INV;
-                        } else {
-                            v = e; d0 = e0; d1 = e1;
-                        }
+                        v[0] = e[0] + e[2]; v[1] = e[1] + e[3];
+                        d0[0] = e0[0] + e0[2]; d0[1] = e0[1] + e0[3];
+                        d1[0] = e1[0] + e1[2]; d1[1] = e1[1] + e1[3];
                     }
                 }
             }
@@ -574,9 +603,15 @@ struct bsdfd_ctx {
     int device, num_cu;
     ImgLayout L;
     char* d_img;
+    // profiling: a ring of HIP event pairs recorded on the launch stream around every launch
+    static constexpr int RING = 64;
     bool profiling;
-    hipEvent_t ev0, ev1;
-    bool ev_valid;
+    hipEvent_t ev0[RING], ev1[RING];
+    bool pending[RING];
+    long long n_rec;       // launches recorded since profiling was enabled
+    long long n_done;      // launches harvested
+    double total_ms;
+    float last_ms;
 };
 
 namespace {
@@ -666,7 +701,7 @@ std::vector<char> build_image(const bsdfd_desc& d, int prec, ImgLayout& L) {
                             const size_t idx = ((((size_t)layer * NM + mo) * KC + kc) * 64 + l) * 8 + j;
                             const float hi = f16_round(w);
                             H(L.wh)[idx] = f32_to_f16_bits(w);
-                            if (prec == BSDFD_PREC_SPLIT3) H(L.wh_lo)[idx] = f32_to_f16_bits((w - hi) * LO_SCALE);
+                            if (prec == BSDFD_PREC_SPLIT3) H(L.wh_lo)[idx] = f32_to_f16_bits(w - hi);
                         }
         for (int kc = 0; kc < KC; ++kc)
             for (int l = 0; l < 64; ++l)
@@ -676,7 +711,7 @@ std::vector<char> build_image(const bsdfd_desc& d, int prec, ImgLayout& L) {
                     const float w = d.w_out[(o & 1) * W + k];
                     float val;
                     if (o < 2) val = w;
-                    else val = (prec == BSDFD_PREC_SPLIT3) ? (w - f16_round(w)) * LO_SCALE : 0.0f;
+                    else val = (prec == BSDFD_PREC_SPLIT3) ? (w - f16_round(w)) : 0.0f;
                     H(L.wo)[((size_t)kc * 64 + l) * 8 + j] = f32_to_f16_bits(val);
                 }
     }
@@ -685,15 +720,26 @@ std::vector<char> build_image(const bsdfd_desc& d, int prec, ImgLayout& L) {
 
 template <int DOMAIN, int NM, int PREC>
 hipError_t launch_jac(bool jac, dim3 grid, dim3 block, size_t lds, hipStream_t s, const KParams& kp) {
+    // dynamic LDS above the default cap needs the attribute; it is per function and per device,
+    // and only ever raised (the largest image is 160 KiB), so set it to the maximum once.
+    static thread_local int attr_dev_t = -1, attr_dev_f = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     if (jac) {
         auto k = flow_kernel<DOMAIN, NM, PREC, true>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+        if (attr_dev_t != dev) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_dev_t = dev;
+        }
         hipLaunchKernelGGL(k, grid, block, lds, s, kp);
     } else {
         auto k = flow_kernel<DOMAIN, NM, PREC, false>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
+        if (attr_dev_f != dev) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_dev_f = dev;
+        }
         hipLaunchKernelGGL(k, grid, block, lds, s, kp);
     }
     return hipGetLastError();
@@ -706,6 +752,19 @@ hipError_t launch_prec(int prec, bool jac, dim3 grid, dim3 block, size_t lds, hi
         case BSDFD_PREC_F16: return launch_jac<DOMAIN, NM, BSDFD_PREC_F16>(jac, grid, block, lds, s, kp);
         default: return launch_jac<DOMAIN, NM, BSDFD_PREC_SPLIT3>(jac, grid, block, lds, s, kp);
     }
+}
+
+hipError_t harvest(bsdfd_handle h, int slot) {
+    hipError_t e = hipEventSynchronize(h->ev1[slot]);
+    if (e != hipSuccess) return e;
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, h->ev0[slot], h->ev1[slot]);
+    if (e != hipSuccess) return e;
+    h->pending[slot] = false;
+    h->total_ms += ms;
+    h->last_ms = ms;
+    h->n_done++;
+    return hipSuccess;
 }
 
 int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, uint64_t seed, uint64_t offset,
@@ -744,7 +803,12 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     dim3 grid((unsigned)(want < cap ? want : cap)), block(threads);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool jac = op != OP_SAMPLES_ONLY;
-    if (h->profiling) HIP_TRY(hipEventRecord(h->ev0, s));
+    int slot = -1;
+    if (h->profiling) {
+        slot = (int)(h->n_rec % bsdfd_ctx::RING);
+        if (h->pending[slot]) HIP_TRY(harvest(h, slot));
+        HIP_TRY(hipEventRecord(h->ev0[slot], s));
+    }
     hipError_t e;
     if (h->domain == BSDFD_DOMAIN_DISK)
         e = NM == 2 ? launch_prec<BSDFD_DOMAIN_DISK, 2>(h->precision, jac, grid, block, h->L.total, s, kp)
@@ -754,8 +818,9 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
                     : launch_prec<BSDFD_DOMAIN_SPHERICAL, 4>(h->precision, jac, grid, block, h->L.total, s, kp);
     if (e != hipSuccess) return fail(BSDFD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     if (h->profiling) {
-        HIP_TRY(hipEventRecord(h->ev1, s));
-        h->ev_valid = true;
+        HIP_TRY(hipEventRecord(h->ev1[slot], s));
+        h->pending[slot] = true;
+        h->n_rec++;
     }
     return BSDFD_OK;
 }
@@ -791,7 +856,9 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     h->state_dim = d->domain == BSDFD_DOMAIN_DISK ? 2 : 3;
     h->in_dim = h->state_dim + 1 + 2 + 4 * PE_BANDS;
     h->device = dev; h->num_cu = prop.multiProcessorCount;
-    h->profiling = false; h->ev_valid = false; h->d_img = nullptr;
+    h->profiling = false; h->d_img = nullptr;
+    h->n_rec = h->n_done = 0; h->total_ms = 0.0; h->last_ms = -1.0f;
+    for (int i = 0; i < bsdfd_ctx::RING; ++i) { h->pending[i] = false; h->ev0[i] = nullptr; h->ev1[i] = nullptr; }
     std::vector<char> img = build_image(*d, prec, h->L);
     if (h->L.total > 160 * 1024 - 512) {
         delete h;
@@ -799,10 +866,16 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_img), img.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_img, img.data(), img.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
-    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    for (int i = 0; i < bsdfd_ctx::RING && e == hipSuccess; ++i) {
+        e = hipEventCreate(&h->ev0[i]);
+        if (e == hipSuccess) e = hipEventCreate(&h->ev1[i]);
+    }
     if (e != hipSuccess) {
-        if (h->d_img) hipFree(h->d_img);
+        if (h->d_img) (void)hipFree(h->d_img);
+        for (int i = 0; i < bsdfd_ctx::RING; ++i) {
+            if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
+            if (h->ev1[i]) (void)hipEventDestroy(h->ev1[i]);
+        }
         delete h;
         return fail(BSDFD_EHIP, std::string("create: ") + hipGetErrorString(e));
     }
@@ -853,8 +926,10 @@ int bsdfd_create_from_file(const char* path, int32_t precision, bsdfd_handle* ou
 void bsdfd_destroy(bsdfd_handle h) {
     if (!h) return;
     if (h->d_img) (void)hipFree(h->d_img);
-    (void)hipEventDestroy(h->ev0);
-    (void)hipEventDestroy(h->ev1);
+    for (int i = 0; i < bsdfd_ctx::RING; ++i) {
+        (void)hipEventDestroy(h->ev0[i]);
+        (void)hipEventDestroy(h->ev1[i]);
+    }
     delete h;
 }
 
@@ -910,17 +985,31 @@ int bsdfd_flow_samples_only(bsdfd_handle h, const float* omega_i, const float* x
 
 int bsdfd_set_profiling(bsdfd_handle h, int32_t enable) {
     if (!h) return fail(BSDFD_EINVAL, "null handle");
+    for (int i = 0; i < bsdfd_ctx::RING; ++i)
+        if (h->pending[i]) HIP_TRY(harvest(h, i));
     h->profiling = enable != 0;
-    h->ev_valid = false;
+    h->n_rec = h->n_done = 0;
+    h->total_ms = 0.0;
+    h->last_ms = -1.0f;
+    return BSDFD_OK;
+}
+
+int bsdfd_profile_read(bsdfd_handle h, int64_t* n_launches, double* total_ms) {
+    if (!h) return fail(BSDFD_EINVAL, "null handle");
+    // harvest in launch order so last_ms is the most recent launch
+    for (long long k = h->n_done; k < h->n_rec; ++k) {
+        const int slot = (int)(k % bsdfd_ctx::RING);
+        if (h->pending[slot]) HIP_TRY(harvest(h, slot));
+    }
+    if (n_launches) *n_launches = h->n_done;
+    if (total_ms) *total_ms = h->total_ms;
     return BSDFD_OK;
 }
 
 float bsdfd_last_kernel_ms(bsdfd_handle h) {
-    if (!h || !h->profiling || !h->ev_valid) return -1.0f;
-    if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.0f;
-    float ms = -1.0f;
-    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.0f;
-    return ms;
+    if (!h || !h->profiling || h->n_rec == 0) return -1.0f;
+    if (bsdfd_profile_read(h, nullptr, nullptr) != BSDFD_OK) return -1.0f;
+    return h->last_ms;
 }
 
 const char* bsdfd_last_error(void) { return g_err.c_str(); }

@@ -1,0 +1,145 @@
+"""Shared machinery of the three ``MyBSDF`` plugin mirrors.
+
+The reference's plugins are ``mi.BSDF`` subclasses whose ``sample``/``pdf`` bodies are
+tensor code between two DrJit<->torch hand-offs (rendering/brdf_measured_disk.py:59-124).
+Here the tensor core is Mitsuba-free (``sample_t`` / ``pdf_t`` — one fused kernel launch
+each, warps and guards included) and the ``mi.BSDF`` protocol methods are thin shims over
+it, so the same class serves a torch-only host (tests, bench, the wavefront harness) and,
+when ``mitsuba`` is importable, the Mitsuba adapter (mitsuba_adapter.py).
+"""
+from __future__ import annotations
+
+import dataclasses
+import os
+from typing import Any, Optional
+
+import torch
+
+from . import _lib
+from . import weights as W
+from .sampler import FlowSampler
+
+# mi.BSDFFlags values used by the reference (rendering/brdf_measured_disk.py:55,
+# rendering/bsdf_myresult.py:56,90)
+FLAG_DIFFUSE_REFLECTION = 0x8
+FLAG_DIFFUSE_TRANSMISSION = 0x10
+FLAG_DELTA_REFLECTION = 0x100
+FLAG_FRONT_SIDE = 0x10000
+FLAG_BACK_SIDE = 0x20000
+
+
+@dataclasses.dataclass
+class BSDFSample3f:
+    """Torch-side stand-in for ``mi.BSDFSample3f`` (fields the reference fills, :76-87)."""
+    wo: torch.Tensor
+    pdf: torch.Tensor
+    eta: Any = 1.0
+    sampled_type: Any = 0
+    sampled_component: int = 0
+
+
+@dataclasses.dataclass
+class SurfaceInteraction:
+    """Minimal ``si``: the plugins only read ``si.wi`` ([N,3], local shading frame)."""
+    wi: torch.Tensor
+
+
+def rgb2lum(rgb: torch.Tensor) -> torch.Tensor:
+    """rendering/utils/mitsuba_brdf_draw.py:36-38."""
+    return 0.2126 * rgb[..., 0] + 0.7152 * rgb[..., 1] + 0.0722 * rgb[..., 2]
+
+
+def _wi_of(si) -> torch.Tensor:
+    wi = si.wi if hasattr(si, "wi") else si
+    if not isinstance(wi, torch.Tensor):
+        wi = wi.torch()  # DrJit array
+    return wi.detach().to(torch.float32).contiguous()
+
+
+def _vec(v) -> torch.Tensor:
+    if not isinstance(v, torch.Tensor):
+        v = v.torch()
+    return v.detach().to(torch.float32).contiguous()
+
+
+class NeuralBSDFCore:
+    """Weights + the fused sampler for one material; subclasses fix domain/variant/T."""
+
+    DOMAIN = W.DOMAIN_DISK
+    DOMAIN_NAME = "disk"
+    VARIANT = _lib.PLUGIN_MEASURED
+    T = 4
+
+    def __init__(self, props):
+        self.props = props
+        get = (lambda k, d=None: props[k] if k in props else d) if hasattr(props, "__contains__") else \
+              (lambda k, d=None: getattr(props, k, d))
+        self._get = get
+        self.material = self._material_name()
+        self.precision = get("precision", "default")
+        self.T = int(get("T", type(self).T))
+        self.bsdf = get("bsdf", None)  # ground-truth evaluator: object with .eval(ctx, si, wo) -> [N,3]
+        self.albedo = torch.tensor(get("albedo", [1.0, 1.0, 1.0]), dtype=torch.float32)
+        fw = self._load_weights(get("weights", None), get("checkpoint_dir", None))
+        self.sampler = FlowSampler(fw, precision=self.precision)
+
+    # -- weight discovery ------------------------------------------------
+    def _material_name(self) -> str:
+        return str(self._get("filename"))
+
+    def _ckpt_tag(self) -> str:
+        return self.material
+
+    def _load_weights(self, path: Optional[str], ckpt_dir: Optional[str]) -> W.FlowWeights:
+        if path is None:
+            path = W.shipped_path(self.material, self.DOMAIN_NAME)
+        if os.path.exists(path):
+            return W.load(path)
+        if ckpt_dir is not None:
+            # the reference's pickle layout: checkpoints_new/<mat>_<domain>/brdf_{rectify,pretrain}_network<tag>.pth
+            d = os.path.join(ckpt_dir, f"{self.material}_{self.DOMAIN_NAME}")
+            tag = self._ckpt_tag()
+            sd = torch.load(os.path.join(d, f"brdf_rectify_network{tag}.pth"), map_location="cpu")
+            bd = torch.load(os.path.join(d, f"brdf_pretrain_network{tag}.pth"), map_location="cpu")
+            return W.from_state_dicts(self.material, self.DOMAIN, sd, bd)
+        raise FileNotFoundError(f"no weights for material {self.material!r} ({self.DOMAIN_NAME}): {path}")
+
+    # -- tensor core -------------------------------------------------------
+    def sample_t(self, wi: torch.Tensor, x0: Optional[torch.Tensor] = None, seed: Optional[int] = None,
+                 offset: int = 0):
+        """wi [N,3] -> (wo [N,3], pdf_sa [N]) with the warp and guards of sample() fused;
+        the firefly rule is separate (``apply_firefly_clamp``) because it needs eval()."""
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        return self.sampler.plugin_sample(wi, x0, T=self.T, variant=self.VARIANT, seed=seed, offset=offset)
+
+    def pdf_t(self, wi: torch.Tensor, wo: torch.Tensor) -> torch.Tensor:
+        return self.sampler.plugin_pdf(wi, wo, T=self.T, variant=self.VARIANT)
+
+    @staticmethod
+    def apply_firefly_clamp(pdf: torch.Tensor, weight_lum: torch.Tensor, thr: float) -> torch.Tensor:
+        """``pdf = where(lum(f/pdf) < thr, pdf, 0)`` (rendering/brdf_measured_disk.py:97-100 thr=30,
+        brdf_measured_spherical.py:106-108 thr=30, bsdf_myresult.py:100-103 thr=3.5)."""
+        return torch.where(weight_lum < thr, pdf, torch.zeros_like(pdf))
+
+    # -- mi.BSDF protocol ----------------------------------------------------
+    def _need_bsdf(self):
+        if self.bsdf is None:
+            raise RuntimeError("eval() delegates to a ground-truth BSDF (Mitsuba's `measured` plugin in the "
+                               "reference, rendering/brdf_measured_disk.py:36-42); pass props['bsdf']")
+        return self.bsdf
+
+    def eval(self, ctx, si, wo, active=True):
+        wi, wo_t = _wi_of(si), _vec(wo)
+        value = _vec(self._need_bsdf().eval(ctx, si, wo)) * self.albedo.to(wi.device)
+        ok = (wi[:, 2] > 0) & (wo_t[:, 2] > 0)
+        return torch.where(ok[:, None], value, torch.zeros_like(value))
+
+    def pdf(self, ctx, si, wo, active=True):
+        return self.pdf_t(_wi_of(si), _vec(wo))
+
+    def eval_pdf(self, ctx, si, wo, active=True):
+        return self.eval(ctx, si, wo, active), self.pdf(ctx, si, wo, active)
+
+    def to_string(self):
+        return "MyBSDF[\n" "    albedo=%s,\n" "]" % (self.albedo.tolist(),)

@@ -87,6 +87,12 @@ class FlowSampler:
     def set_profiling(self, on: bool):
         _lib.check(self._L.bsdfd_set_profiling(self._h, 1 if on else 0))
 
+    def profile_read(self):
+        """(launches, total kernel ms) since ``set_profiling(True)`` — HIP events on the launch stream."""
+        n, ms = C.c_int64(), C.c_double()
+        _lib.check(self._L.bsdfd_profile_read(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def last_kernel_ms(self) -> float:
         return float(self._L.bsdfd_last_kernel_ms(self._h))
 

@@ -122,11 +122,15 @@ int bsdfd_plugin_pdf(bsdfd_handle h, int32_t variant, const float* wi, const flo
 int bsdfd_flow_samples_only(bsdfd_handle h, const float* omega_i, const float* x0, int64_t N,
                             int32_t T, float* x_out, void* hip_stream);
 
-/* Timing of the most recent kernel launched through this handle on `hip_stream`:
- * the library brackets every launch with a pair of HIP events on the launch stream when
- * profiling is enabled. Returns the kernel's duration in milliseconds (synchronises on the
- * stop event), or a negative value if profiling is disabled / nothing was launched. */
+/* Kernel timing with HIP events ON THE LAUNCH STREAM: while profiling is enabled every launch
+ * through this handle is bracketed by an event pair recorded on the stream the kernel is
+ * launched on (a ring of 64 pairs; no host synchronisation unless the ring wraps onto a launch
+ * that is still running).  bsdfd_set_profiling resets the counters.
+ * bsdfd_profile_read synchronises on the outstanding stop events and returns the number of
+ * launches and the sum of their durations (ms) since profiling was enabled;
+ * bsdfd_last_kernel_ms returns the duration of the most recent launch (negative if none). */
 int bsdfd_set_profiling(bsdfd_handle h, int32_t enable);
+int bsdfd_profile_read(bsdfd_handle h, int64_t* n_launches, double* total_ms);
 float bsdfd_last_kernel_ms(bsdfd_handle h);
 
 const char* bsdfd_last_error(void);
