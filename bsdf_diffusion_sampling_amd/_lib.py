@@ -60,6 +60,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # Load PyTorch's bundled HIP runtime FIRST: libbsdfd.so needs libamdhip64.so.7 and must bind to
+    # the same runtime instance torch uses (two HIP runtimes in one process do not share devices,
+    # streams or allocations: the second one reports "no ROCm-capable device").
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, fp = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
     L.bsdfd_create.argtypes = [C.POINTER(Desc), C.POINTER(vp)]

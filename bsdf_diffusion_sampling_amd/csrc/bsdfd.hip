@@ -57,6 +57,7 @@ enum { IO_OPERATOR = 0, IO_PLUGIN = 1, IO_PLUGIN_FULLSPHERE = 2 };
 
 struct ImgLayout {  // byte offsets into the weight image (identical in global memory and LDS)
     int win, wc, wh, wh_lo, wo, bw1, bb1, bw2, bb2, total;
+    int wc16, wc16_lo, bw1_16, bw1_16_lo, bw2_16a, bw2_16b;  // fp16 A-fragments of the per-query prologue
 };
 
 struct KParams {
@@ -204,7 +205,7 @@ __device__ float von_mises_sample(float mu, float kappa, unsigned k0, unsigned k
 //   PREC   : BSDFD_PREC_F32 / SPLIT3 / F16      JAC : track the Jacobian determinant
 // ---------------------------------------------------------------------------------------------
 template <int DOMAIN, int NM, int PREC, bool JAC>
-__global__ __launch_bounds__(512) void flow_kernel(const KParams p) {
+__global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     {
         const uint4* src = reinterpret_cast<const uint4*>(p.img);
@@ -244,12 +245,17 @@ __global__ __launch_bounds__(512) void flow_kernel(const KParams p) {
     }
 
     const bool reverse = (p.op == OP_PDF);
-    const float invT = (float)(1.0 / (double)p.T);
+    const double invT_d = 1.0 / (double)p.T;
+    const float invT = (float)invT_d;
     const float cstep = reverse ? -invT : invT;
     const long long ntiles = (p.N + 15) / 16;
 
-    for (long long tile = (long long)blockIdx.x * waves_per_block + wave; tile < ntiles;
-         tile += (long long)gridDim.x * waves_per_block) {
+    // each workgroup owns a CONTIGUOUS range of tiles (its waves interleave inside it), so the
+    // 128-B lines of the query arrays are fetched by one XCD's L2 only — no cross-XCD over-fetch
+    const long long tiles_per_block = (ntiles + gridDim.x - 1) / gridDim.x;
+    const long long tile_begin = (long long)blockIdx.x * tiles_per_block;
+    const long long tile_end = tile_begin + tiles_per_block < ntiles ? tile_begin + tiles_per_block : ntiles;
+    for (long long tile = tile_begin + wave; tile < tile_end; tile += waves_per_block) {
         const long long qi_raw = tile * 16 + q;
         const bool valid = qi_raw < p.N;
         const long long qi = valid ? qi_raw : p.N - 1;
@@ -304,19 +310,18 @@ __global__ __launch_bounds__(512) void flow_kernel(const KParams p) {
         }
         const float yslab = g == 0 ? y0 : (g == 1 ? y1 : 0.0f);
 
-        // conditioning part of layer 1, constant across the Euler steps
+        // conditioning part of layer 1 (constant across the Euler steps) and the base-density net
+        // PE_3 -> 16 (SiLU) -> 4, once per query
         f32x4 cacc[NM];
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-            f32x4 a = zero4;
-#pragma unroll
-            for (int s = 0; s < PE_BANDS; ++s) a = mfma4(Lwc[(m * PE_SLABS + s) * 64 + lane], pe[s], a);
-            cacc[m] = mfma4(Lwc[(m * PE_SLABS + PE_BANDS) * 64 + lane], yslab, a);
-        }
-
-        // ---------------- base-density net: PE_3 -> 16 (SiLU) -> 4 -------------------------------
         f32x4 bo;
-        {
+        if (PREC == BSDFD_PREC_F32) {
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                f32x4 a = zero4;
+#pragma unroll
+                for (int s = 0; s < PE_BANDS; ++s) a = mfma4(Lwc[(m * PE_SLABS + s) * 64 + lane], pe[s], a);
+                cacc[m] = mfma4(Lwc[(m * PE_SLABS + PE_BANDS) * 64 + lane], yslab, a);
+            }
             f32x4 bz = *reinterpret_cast<const f32x4*>(Lbb1 + lane * 4);
 #pragma unroll
             for (int s = 0; s < BASE_PE_BANDS; ++s) bz = mfma4(Lbw1[s * 64 + lane], pe[s], bz);
@@ -325,6 +330,41 @@ __global__ __launch_bounds__(512) void flow_kernel(const KParams p) {
             bo = *reinterpret_cast<const f32x4*>(Lbb2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) bo = mfma4(w2[r], silu(bz[r]), bo);
+        } else {
+            // one K=32 fp16 fragment holds the lane's 5 band values + its raw coordinate:
+            // k = (g, j): j < 5 -> band j, j = 5 -> y slab, j = 6,7 -> 0; split hi + lo
+            Frag ph, pl;
+            {
+                const float v0[4] = {pe[0], pe[1], pe[2], pe[3]};
+                const float v1[4] = {pe[4], yslab, 0.0f, 0.0f};
+                split_pack<true>(v0, ph.p[0], ph.p[1], pl.p[0], pl.p[1]);
+                split_pack<true>(v1, ph.p[2], ph.p[3], pl.p[2], pl.p[3]);
+            }
+            const f16x8* Lwc16 = reinterpret_cast<const f16x8*>(smem + p.L.wc16);
+            const f16x8* Lwc16l = reinterpret_cast<const f16x8*>(smem + p.L.wc16_lo);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const f16x8 ah = Lwc16[m * 64 + lane], al = Lwc16l[m * 64 + lane];
+                f32x4 a = mfma16(ah, ph.v, zero4);
+                a = mfma16(ah, pl.v, a);
+                cacc[m] = mfma16(al, ph.v, a);
+            }
+            const f16x8 b1h = *reinterpret_cast<const f16x8*>(smem + p.L.bw1_16 + lane * 16);
+            const f16x8 b1l = *reinterpret_cast<const f16x8*>(smem + p.L.bw1_16_lo + lane * 16);
+            f32x4 bz = *reinterpret_cast<const f32x4*>(Lbb1 + lane * 4);
+            bz = mfma16(b1h, ph.v, bz);
+            bz = mfma16(b1h, pl.v, bz);
+            bz = mfma16(b1l, ph.v, bz);
+            // output layer, K = 16 hidden units: B = [h hi (j<4) | h lo (j>=4)], A = [W2 hi | W2 hi]
+            // gives hi*hi + hi*lo in one MFMA; the second, A = [W2 lo | 0], adds lo*hi.
+            Frag bq;
+            {
+                const float hv[4] = {silu(bz[0]), silu(bz[1]), silu(bz[2]), silu(bz[3])};
+                split_pack<true>(hv, bq.p[0], bq.p[1], bq.p[2], bq.p[3]);
+            }
+            bo = *reinterpret_cast<const f32x4*>(Lbb2);
+            bo = mfma16(*reinterpret_cast<const f16x8*>(smem + p.L.bw2_16a + lane * 16), bq.v, bo);
+            bo = mfma16(*reinterpret_cast<const f16x8*>(smem + p.L.bw2_16b + lane * 16), bq.v, bo);
         }
         // bo = (loc0, loc1, ls0, ls1) disk | (loc, log_scale, mu, kappa_raw) spherical
         float kappa = 0.0f;
@@ -368,8 +408,10 @@ __global__ __launch_bounds__(512) void flow_kernel(const KParams p) {
         // ---------------- T explicit Euler steps ---------------------------------------------------
         float acc = 1.0f;
         for (int t = 0; t < p.T; ++t) {
-            const float alpha = reverse ? (float)(1.0 - (double)t / (double)p.T)
-                                        : (float)((double)t / (double)p.T);
+            // alpha = float32(t/T) resp. float32(1 - t/T) as torch forms them (python double, then
+            // cast); t * (1/T) in fp64 differs from t/T by < 1 ulp(fp64), invisible after the cast.
+            const double tf = (double)t * invT_d;
+            const float alpha = (float)(reverse ? 1.0 - tf : tf);
             f32x4 z[NM], zt0[NM], zt1[NM];
             if (DOMAIN == BSDFD_DOMAIN_DISK) {
                 const float bs = sel4(g, x0, x1, alpha, 0.0f);
@@ -601,6 +643,8 @@ int fail(int code, const std::string& msg) {
 struct bsdfd_ctx {
     int domain, width, n_hidden, precision, state_dim, in_dim;
     int device, num_cu;
+    int per_cu[2];  // resident blocks per CU of the (no-Jacobian, Jacobian) kernel instantiation
+    const void* kfun[2];
     ImgLayout L;
     char* d_img;
     // profiling: a ring of HIP event pairs recorded on the launch stream around every launch
@@ -645,6 +689,15 @@ std::vector<char> build_image(const bsdfd_desc& d, int prec, ImgLayout& L) {
         if (prec == BSDFD_PREC_SPLIT3) off += (NH - 1) * NM * KC * 64 * 16;
         L.wo = off; off += KC * 64 * 16;
     }
+    L.wc16 = L.wc16_lo = L.bw1_16 = L.bw1_16_lo = L.bw2_16a = L.bw2_16b = 0;
+    if (prec != BSDFD_PREC_F32) {
+        L.wc16 = off; off += NM * 64 * 16;
+        L.wc16_lo = off; off += NM * 64 * 16;
+        L.bw1_16 = off; off += 64 * 16;
+        L.bw1_16_lo = off; off += 64 * 16;
+        L.bw2_16a = off; off += 64 * 16;
+        L.bw2_16b = off; off += 64 * 16;
+    }
     L.bw1 = off; off += (BASE_PE_BANDS + 1) * 64 * 4;
     L.bb1 = off; off += 64 * 16;
     L.bw2 = off; off += 64 * 16;
@@ -675,6 +728,34 @@ std::vector<char> build_image(const bsdfd_desc& d, int prec, ImgLayout& L) {
         }
     }
     for (int r = 0; r < 4; ++r) F(L.bb2)[r] = d.base_b2[r];
+
+    if (prec != BSDFD_PREC_F32) {
+        auto put = [&](int off_hi, int off_lo, size_t idx, float w) {
+            H(off_hi)[idx] = f32_to_f16_bits(w);
+            if (off_lo) H(off_lo)[idx] = f32_to_f16_bits(w - f16_round(w));
+        };
+        for (int l = 0; l < 64; ++l) {
+            const int g = l >> 4, i = l & 15;
+            for (int j = 0; j < 8; ++j) {
+                // K position (g, j): j < 5 band j of (dim g&1, fn g>>1); j = 5 raw coordinate; else 0
+                for (int m = 0; m < NM; ++m) {
+                    const int unit = 16 * m + i;
+                    float w = 0.0f;
+                    if (j < PE_BANDS) w = d.w_in[unit * IN + SD + 1 + 2 + 4 * j + 2 * (g >> 1) + (g & 1)];
+                    else if (j == PE_BANDS && g < 2) w = d.w_in[unit * IN + SD + 1 + g];
+                    put(L.wc16, L.wc16_lo, ((size_t)m * 64 + l) * 8 + j, w);
+                }
+                float wb = 0.0f;
+                if (j < BASE_PE_BANDS) wb = d.base_w1[i * BIN + 2 + 4 * j + 2 * (g >> 1) + (g & 1)];
+                else if (j == PE_BANDS && g < 2) wb = d.base_w1[i * BIN + g];
+                put(L.bw1_16, L.bw1_16_lo, (size_t)l * 8 + j, wb);
+                // base output layer: k = hidden unit 4g + (j&3); j < 4 pairs with h_hi, j >= 4 with h_lo
+                const float w2 = d.base_w2[(i & 3) * BASE_HIDDEN + 4 * g + (j & 3)];
+                H(L.bw2_16a)[(size_t)l * 8 + j] = f32_to_f16_bits(w2);
+                H(L.bw2_16b)[(size_t)l * 8 + j] = f32_to_f16_bits(j < 4 ? w2 - f16_round(w2) : 0.0f);
+            }
+        }
+    }
 
     if (prec == BSDFD_PREC_F32) {
         for (int layer = 0; layer < NH - 1; ++layer)
@@ -718,41 +799,28 @@ std::vector<char> build_image(const bsdfd_desc& d, int prec, ImgLayout& L) {
     return img;
 }
 
-template <int DOMAIN, int NM, int PREC>
-hipError_t launch_jac(bool jac, dim3 grid, dim3 block, size_t lds, hipStream_t s, const KParams& kp) {
-    // dynamic LDS above the default cap needs the attribute; it is per function and per device,
-    // and only ever raised (the largest image is 160 KiB), so set it to the maximum once.
-    static thread_local int attr_dev_t = -1, attr_dev_f = -1;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (jac) {
-        auto k = flow_kernel<DOMAIN, NM, PREC, true>;
-        if (attr_dev_t != dev) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr_dev_t = dev;
-        }
-        hipLaunchKernelGGL(k, grid, block, lds, s, kp);
-    } else {
-        auto k = flow_kernel<DOMAIN, NM, PREC, false>;
-        if (attr_dev_f != dev) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr_dev_f = dev;
-        }
-        hipLaunchKernelGGL(k, grid, block, lds, s, kp);
-    }
-    return hipGetLastError();
-}
-
+// kernel instantiation table
 template <int DOMAIN, int NM>
-hipError_t launch_prec(int prec, bool jac, dim3 grid, dim3 block, size_t lds, hipStream_t s, const KParams& kp) {
+const void* kernel_ptr_prec(int prec, bool jac) {
     switch (prec) {
-        case BSDFD_PREC_F32: return launch_jac<DOMAIN, NM, BSDFD_PREC_F32>(jac, grid, block, lds, s, kp);
-        case BSDFD_PREC_F16: return launch_jac<DOMAIN, NM, BSDFD_PREC_F16>(jac, grid, block, lds, s, kp);
-        default: return launch_jac<DOMAIN, NM, BSDFD_PREC_SPLIT3>(jac, grid, block, lds, s, kp);
+        case BSDFD_PREC_F32:
+            return jac ? reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F32, true>)
+                       : reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F32, false>);
+        case BSDFD_PREC_F16:
+            return jac ? reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F16, true>)
+                       : reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F16, false>);
+        default:
+            return jac ? reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_SPLIT3, true>)
+                       : reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_SPLIT3, false>);
     }
 }
+const void* kernel_ptr(int domain, int nm, int prec, bool jac) {
+    if (domain == BSDFD_DOMAIN_DISK)
+        return nm == 2 ? kernel_ptr_prec<BSDFD_DOMAIN_DISK, 2>(prec, jac) : kernel_ptr_prec<BSDFD_DOMAIN_DISK, 4>(prec, jac);
+    return nm == 2 ? kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 2>(prec, jac)
+                   : kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 4>(prec, jac);
+}
+inline int threads_for(int nm) { return nm == 2 ? 256 : 512; }
 
 hipError_t harvest(bsdfd_handle h, int slot) {
     hipError_t e = hipEventSynchronize(h->ev1[slot]);
@@ -790,16 +858,22 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     kp.N = N; kp.T = T; kp.n_hidden = h->n_hidden; kp.op = op; kp.io = io; kp.seed = seed; kp.offset = offset;
 
     const int NM = h->width / 16;
-    const int threads = NM == 2 ? 256 : 512;
+    const int threads = threads_for(NM);
     const int waves = threads / 64;
     const long long ntiles = (N + 15) / 16;
     const long long want = (ntiles + waves - 1) / waves;
-    // LDS-limited residency: 160 KiB per CU
-    int per_cu = (int)(160 * 1024 / (h->L.total + 256));
-    if (per_cu > 8) per_cu = 8;
-    if (per_cu * waves > 32) per_cu = 32 / waves;
+    // persistent grid: exactly the resident capacity (blocks per CU from the occupancy query of the
+    // instantiated kernel: VGPR- or LDS-limited), each wave then walks its share of the tiles
+    const bool jac_ = op != OP_SAMPLES_ONLY;
+    int per_cu = h->per_cu[jac_ ? 1 : 0];
     if (per_cu < 1) per_cu = 1;
-    const long long cap = (long long)h->num_cu * per_cu;
+    if (const char* ov = std::getenv("BSDFD_BLOCKS_PER_CU")) {  // tuning knob (tools/tscan.py)
+        const int v = std::atoi(ov);
+        if (v > 0) per_cu = v;
+    }
+    // 4 rounds of resident blocks: block-granular dynamic balancing measured ~4 % faster than an
+    // exactly-resident persistent grid (tools/tscan.py sweep)
+    const long long cap = (long long)h->num_cu * per_cu * 4;
     dim3 grid((unsigned)(want < cap ? want : cap)), block(threads);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool jac = op != OP_SAMPLES_ONLY;
@@ -809,13 +883,9 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
         if (h->pending[slot]) HIP_TRY(harvest(h, slot));
         HIP_TRY(hipEventRecord(h->ev0[slot], s));
     }
-    hipError_t e;
-    if (h->domain == BSDFD_DOMAIN_DISK)
-        e = NM == 2 ? launch_prec<BSDFD_DOMAIN_DISK, 2>(h->precision, jac, grid, block, h->L.total, s, kp)
-                    : launch_prec<BSDFD_DOMAIN_DISK, 4>(h->precision, jac, grid, block, h->L.total, s, kp);
-    else
-        e = NM == 2 ? launch_prec<BSDFD_DOMAIN_SPHERICAL, 2>(h->precision, jac, grid, block, h->L.total, s, kp)
-                    : launch_prec<BSDFD_DOMAIN_SPHERICAL, 4>(h->precision, jac, grid, block, h->L.total, s, kp);
+    void* args[] = {const_cast<KParams*>(&kp)};
+    hipError_t e = hipLaunchKernel(h->kfun[jac ? 1 : 0], grid, block, args, (size_t)h->L.total, s);
+    if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) return fail(BSDFD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     if (h->profiling) {
         HIP_TRY(hipEventRecord(h->ev1[slot], s));
@@ -869,6 +939,15 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     for (int i = 0; i < bsdfd_ctx::RING && e == hipSuccess; ++i) {
         e = hipEventCreate(&h->ev0[i]);
         if (e == hipSuccess) e = hipEventCreate(&h->ev1[i]);
+    }
+    for (int jac = 0; jac < 2 && e == hipSuccess; ++jac) {
+        h->kfun[jac] = kernel_ptr(h->domain, h->width / 16, prec, jac != 0);
+        // dynamic LDS above the default cap needs the attribute (per function and device)
+        e = hipFuncSetAttribute(h->kfun[jac], hipFuncAttributeMaxDynamicSharedMemorySize, h->L.total);
+        int nb = 0;
+        if (e == hipSuccess)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h->kfun[jac], threads_for(h->width / 16), (size_t)h->L.total);
+        h->per_cu[jac] = nb;
     }
     if (e != hipSuccess) {
         if (h->d_img) (void)hipFree(h->d_img);

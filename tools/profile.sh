@@ -1,0 +1,19 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): kernel-trace stats + separate PMC passes of bench.py.
+# Usage: tools/profile.sh <tag> [bench args...]   -> writes gpurun_out/prof_<tag>/
+set -u
+TAG=${1:-r01}; shift || true
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 10 --warmup 2 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $REPO/bench.py $ARGS > $OUT/trace.log 2>&1
+for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS" \
+           "GRBM_GUI_ACTIVE GRBM_COUNT" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  name=$(echo $grp | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_$name -o pmc -- python3 $REPO/bench.py $ARGS > $OUT/pmc_$name.log 2>&1
+done
+find $OUT -name "*.csv" | head -30

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag>/ directory (written by tools/profile.sh on the GPU box) into
+the committed, judged summaries under profiles/: <name>_kernel_stats.csv (rocprofv3 --kernel-trace
+--stats), <name>_pmc.json (per-launch counter means of the flow kernel) and pmc_latest.json
+(HBM bytes per launch, read by bench.py for roofline.traffic)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag, name = sys.argv[1], sys.argv[2]
+    workload = sys.argv[3] if len(sys.argv) > 3 else "disk_1Mi_T8"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, f"{name}_kernel_stats.csv"))
+    pmc = {}
+    meta = {}
+    for f in sorted(glob.glob(os.path.join(src, "pmc_*", "pmc_counter_collection.csv"))):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "flow_kernel" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
+                                          "SGPR_Count", "Scratch_Size") if k in r}
+        for k, v in agg.items():
+            pmc[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
+    out = {"tag": tag, "workload": workload, "kernel": meta, "counters": pmc}
+    # kernel duration from the trace
+    for r in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))):
+        if "flow_kernel" in r["Name"]:
+            out["kernel_trace"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
+                                   "max_ns": float(r["MaxNs"]), "percentage": float(r["Percentage"])}
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        # rocprofv3 reports KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B: double it
+        # (MI355X_MICROARCH.md §HBM; calibrated on this kernel's known 12/24 B-per-query reads)
+        fetch = pmc["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
+        write = pmc["WRITE_SIZE"]["mean_per_launch"] * 1024
+        out["hbm_bytes_per_launch"] = fetch + write
+        out["hbm_fetch_bytes_corrected"] = fetch
+        out["hbm_write_bytes"] = write
+    json.dump(out, open(os.path.join(dst, f"{name}_pmc.json"), "w"), indent=1)
+    latest = {}
+    lp = os.path.join(dst, "pmc_latest.json")
+    if os.path.exists(lp):
+        latest = json.load(open(lp))
+    if "hbm_bytes_per_launch" in out:
+        latest[workload] = {"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "source": f"{name}_pmc.json"}
+        json.dump(latest, open(lp, "w"), indent=1)
+    print(json.dumps(out, indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    main()
