@@ -85,18 +85,25 @@ __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-// SiLU and its derivative from one sigmoid: h = z*s, g = s*(1 + z*(1-s)) = s + h*(1-s).
+// SiLU and its derivative from one sigmoid.  Every layer's weights are packed so that the MFMA
+// delivers zs = -log2(e) * z ("scaled pre-activation"): then sigma(z) = 1 / (1 + 2^zs) needs no
+// multiply in front of v_exp_f32, the layer's outputs are hs = zs * s = -log2(e) * silu(z) and
+// ts = zts * g = -log2(e) * t, and the NEXT layer's unscaled weights applied to (hs, ts) again
+// deliver scaled pre-activations.  The first layer's weights carry the factor -log2(e), the
+// output layer's carry -ln 2 (host packing, build_image).  silu'(z) = s + silu(z) (1 - s)
+// = fma(hs, -ln2 (1 - s), s).
 // v_exp_f32 / v_rcp_f32 are 1-ulp hardware transcendentals (quarter rate: the two of them are
-// 16 of the ~26 VALU cycles a hidden unit costs).
-__device__ __forceinline__ float sigmoid_fast(float z) {
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896340736f));
+// ~15 of the ~55 VALU cycles a hidden unit costs per step).
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kLn2 = 0.69314718055994530942f;
+__device__ __forceinline__ void silu_grad_scaled(float zs, float& hs, float& g) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zs));
+    hs = zs * s;
+    g = fmaf(hs, fmaf(s, kLn2, -kLn2), s);
 }
-__device__ __forceinline__ void silu_grad(float z, float& h, float& g) {
-    const float s = sigmoid_fast(z);
-    h = z * s;
-    g = fmaf(h, 1.0f - s, s);
+__device__ __forceinline__ float silu(float z) {  // base net: unscaled
+    return z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -kLog2e));
 }
-__device__ __forceinline__ float silu(float z) { return z * sigmoid_fast(z); }
 
 // hi/lo split of an fp32 value into two fp16-representable fp32 values (see header comment)
 __device__ __forceinline__ float hi_part(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFFE000u); }
@@ -250,12 +257,16 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
     const float cstep = reverse ? -invT : invT;
     const long long ntiles = (p.N + 15) / 16;
 
-    // each workgroup owns a CONTIGUOUS range of tiles (its waves interleave inside it), so the
-    // 128-B lines of the query arrays are fetched by one XCD's L2 only — no cross-XCD over-fetch
-    const long long tiles_per_block = (ntiles + gridDim.x - 1) / gridDim.x;
-    const long long tile_begin = (long long)blockIdx.x * tiles_per_block;
-    const long long tile_end = tile_begin + tiles_per_block < ntiles ? tile_begin + tiles_per_block : ntiles;
-    for (long long tile = tile_begin + wave; tile < tile_end; tile += waves_per_block) {
+    // Tile -> wave map: a workgroup takes CHUNKS of 8 x waves_per_block consecutive tiles, chunks
+    // round-robin over the grid.  Consecutive tiles of a chunk stay on one CU (one XCD's L2), so the
+    // 128-B lines of the query arrays are not fetched by two XCDs (a plain round-robin of single
+    // tiles measured +35 % HBM reads), while the round-robin of chunks keeps the dynamic balance.
+    const long long chunk = 8LL * waves_per_block;
+    for (long long it = 0;; ++it) {
+        const long long chunk_base = ((it >> 3) * gridDim.x + blockIdx.x) * chunk;
+        if (chunk_base >= ntiles) break;
+        const long long tile = chunk_base + (it & 7) * waves_per_block + wave;
+        if (tile >= ntiles) continue;
         const long long qi_raw = tile * 16 + q;
         const bool valid = qi_raw < p.N;
         const long long qi = valid ? qi_raw : p.N - 1;
@@ -314,7 +325,11 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
         // PE_3 -> 16 (SiLU) -> 4, once per query
         f32x4 cacc[NM];
         f32x4 bo;
-        if (PREC == BSDFD_PREC_F32) {
+        // fp32 MFMA (exact FMA chains) in every precision mode: this term enters z1 of ALL T steps, so
+        // its rounding error is systematic, not random — an fp16-split version (kept below) doubled
+        // the p99 pdf error for no measurable time saving (12 + 8 K=4 MFMAs once per query).
+        constexpr bool PROLOGUE_F32 = true;
+        if (PROLOGUE_F32 || PREC == BSDFD_PREC_F32) {
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 f32x4 a = zero4;
@@ -435,21 +450,21 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             }
 
             f32x4 v = zero4, d0 = zero4, d1 = zero4;  // rows r=0,1: the two outputs
-            for (int layer = 0; layer < p.n_hidden; ++layer) {
-                const bool last = (layer == p.n_hidden - 1);
-                float h[NM][4], t0[NM][4], t1[NM][4];
+            if (PREC == BSDFD_PREC_F32) {
+                for (int layer = 0; layer < p.n_hidden; ++layer) {
+                    const bool last = (layer == p.n_hidden - 1);
+                    float h[NM][4], t0[NM][4], t1[NM][4];
 #pragma unroll
-                for (int m = 0; m < NM; ++m)
+                    for (int m = 0; m < NM; ++m)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float gg;
-                        silu_grad(z[m][r], h[m][r], gg);
-                        if (JAC) {
-                            t0[m][r] = zt0[m][r] * gg;
-                            t1[m][r] = zt1[m][r] * gg;
+                        for (int r = 0; r < 4; ++r) {
+                            float gg;
+                            silu_grad_scaled(z[m][r], h[m][r], gg);
+                            if (JAC) {
+                                t0[m][r] = zt0[m][r] * gg;
+                                t1[m][r] = zt1[m][r] * gg;
+                            }
                         }
-                    }
-                if (PREC == BSDFD_PREC_F32) {
                     if (!last) {
                         const char* base = Lwh + (size_t)layer * NM * NM * 64 * 16;
 #pragma unroll
@@ -483,25 +498,39 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                             }
                         }
                     }
-                } else {
-                    // fp16 MFMA path.  The lane's own 8 values per K chunk ARE the B fragment; each
-                    // is split into hi + lo (SPLIT3) and the three products share one accumulator.
-                    constexpr bool SPLIT = (PREC == BSDFD_PREC_SPLIT3);
+                }
+            } else {
+                // ---- fp16 MFMA path ----
+                // Per layer: one sigmoid per unit -> (hs, g); tangents scaled by g; the lane's own 8
+                // values per K chunk ARE the B fragment of the next contraction, split into hi + lo
+                // (SPLIT3); the three products share one fp32 accumulator, and the MFMAs are issued
+                // term-major over the 3 x NM accumulators so that no two consecutive MFMAs depend on
+                // each other.  (A software-pipelined variant that interleaved the MFMAs of one vector
+                // with the VALU work of the next measured no faster: on gfx950 a 16x16x32 MFMA hides
+                // only ~3 VALU issues, tools/ubench/mfma_overlap.hip — MFMA and VALU time add.)
+                constexpr bool SPLIT = (PREC == BSDFD_PREC_SPLIT3);
+                for (int layer = 0; layer < p.n_hidden; ++layer) {
+                    const bool last = (layer == p.n_hidden - 1);
                     Frag bh[KC], bl[KC], b0h[KC], b0l[KC], b1h[KC], b1l[KC];
 #pragma unroll
-                    for (int kc = 0; kc < KC; ++kc)
+                    for (int m = 0; m < NM; ++m) {
+                        float hv[4], t0v[4], t1v[4];
 #pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            const int m = 2 * kc + half;
-                            split_pack<SPLIT>(h[m], bh[kc].p[2 * half], bh[kc].p[2 * half + 1], bl[kc].p[2 * half],
-                                              bl[kc].p[2 * half + 1]);
+                        for (int r = 0; r < 4; ++r) {
+                            float gg;
+                            silu_grad_scaled(z[m][r], hv[r], gg);
                             if (JAC) {
-                                split_pack<SPLIT>(t0[m], b0h[kc].p[2 * half], b0h[kc].p[2 * half + 1],
-                                                  b0l[kc].p[2 * half], b0l[kc].p[2 * half + 1]);
-                                split_pack<SPLIT>(t1[m], b1h[kc].p[2 * half], b1h[kc].p[2 * half + 1],
-                                                  b1l[kc].p[2 * half], b1l[kc].p[2 * half + 1]);
+                                t0v[r] = zt0[m][r] * gg;
+                                t1v[r] = zt1[m][r] * gg;
                             }
                         }
+                        const int kc = m >> 1, q0 = 2 * (m & 1);
+                        split_pack<SPLIT>(hv, bh[kc].p[q0], bh[kc].p[q0 + 1], bl[kc].p[q0], bl[kc].p[q0 + 1]);
+                        if (JAC) {
+                            split_pack<SPLIT>(t0v, b0h[kc].p[q0], b0h[kc].p[q0 + 1], b0l[kc].p[q0], b0l[kc].p[q0 + 1]);
+                            split_pack<SPLIT>(t1v, b1h[kc].p[q0], b1h[kc].p[q0 + 1], b1l[kc].p[q0], b1l[kc].p[q0 + 1]);
+                        }
+                    }
                     if (!last) {
                         const size_t lbase = (size_t)layer * NM * KC * 64 * 16;
                         f32x4 a[NM], a0[NM], a1[NM];
@@ -516,7 +545,6 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                                 wh[mo] = *reinterpret_cast<const f16x8*>(Lwh + off);
                                 if (SPLIT) wl[mo] = *reinterpret_cast<const f16x8*>(Lwh_lo + off);
                             }
-                            // term-major order: consecutive MFMAs hit different accumulators
 #pragma unroll
                             for (int mo = 0; mo < NM; ++mo) {
                                 a[mo] = mfma16(wh[mo], bh[kc].v, a[mo]);
@@ -670,7 +698,15 @@ inline float f16_round(float x) { return (float)(_Float16)x; }
 
 // Build the weight image: every matrix is stored as ready-made MFMA A-fragments in the
 // lane order the kernel reads them (see the kernel header for the unit <-> (m, g, r) map).
-std::vector<char> build_image(const bsdfd_desc& d, int prec, ImgLayout& L) {
+std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
+    // scaled pre-activation convention (see silu_grad_scaled): first layer x -log2(e), output layer x -ln 2
+    bsdfd_desc d = d_in;
+    const int sd_ = d.domain == BSDFD_DOMAIN_DISK ? 2 : 3;
+    std::vector<float> w_in_s((size_t)d.width * (sd_ + 1 + 2 + 4 * PE_BANDS)), w_out_s((size_t)2 * d.width);
+    for (size_t i = 0; i < w_in_s.size(); ++i) w_in_s[i] = (float)((double)d_in.w_in[i] * -1.4426950408889634);
+    for (size_t i = 0; i < w_out_s.size(); ++i) w_out_s[i] = (float)((double)d_in.w_out[i] * -0.6931471805599453);
+    d.w_in = w_in_s.data();
+    d.w_out = w_out_s.data();
     const int W = d.width, NM = W / 16, NH = d.n_hidden, KC = NM / 2;
     const int SD = d.domain == BSDFD_DOMAIN_DISK ? 2 : 3;
     const int IN = SD + 1 + 2 + 4 * PE_BANDS;
