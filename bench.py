@@ -6,8 +6,9 @@ A "step" is one pass of the hot path over one batch of synthetic shading queries
 followed by ``MyBSDF.pdf`` on the produced directions — BASELINE.json configs[1]:
 single measured BSDF (aniso_miro_7_rgb), disk-domain net, 1 Mi queries, 8 denoise steps,
 per GPU (weak scaling: every rank gets its own 1 Mi-query sub-batch).  Inputs are resident
-in HBM before the timed region.  With N > 1 ranks each step's (wo, pdf) shard is gathered
-to rank 0 with RCCL on a side stream, overlapped with the next step's compute.
+in HBM before the timed region.  There is no data-path collective; with N > 1 ranks the final
+(wo, pdf) shards are concatenated on rank 0 with one RCCL gather inside the timed region
+(`--gather every` gathers every step's shard on a side stream, overlapped with compute).
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -121,8 +122,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="disk_1Mi_T8", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default="default", choices=["default", "f32", "split3", "f16"])
-    ap.add_argument("--gather", default="root", choices=["root", "none"],
-                    help="N>1: gather each step's (wo,pdf) shard to rank 0 over RCCL (overlapped)")
+    ap.add_argument("--gather", default="final", choices=["final", "every", "none"],
+                    help="N>1: RCCL gather of the (wo,pdf) shards to rank 0 — 'final': the last step's results "
+                         "once, inside the timed region (the path has no data-path collective; the final "
+                         "concatenation is the only exchange); 'every': every step, overlapped on a side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -133,11 +136,18 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU; BSDFD_BENCH_BACKEND=gloo is a TEST hook (several ranks sharing one GPU on a
+    # 1-GPU box, gather staged through host memory) to exercise the N>1 control flow without RCCL
+    backend = os.environ.get("BSDFD_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from bsdf_diffusion_sampling_amd import _lib
     from bsdf_diffusion_sampling_amd import weights as W
@@ -154,10 +164,12 @@ def main():
     wo = [torch.empty((n_local, 3), dtype=torch.float32, device=device) for _ in range(2)]
     pdf_s = [torch.empty((n_local,), dtype=torch.float32, device=device) for _ in range(2)]
     pdf_p = [torch.empty((n_local,), dtype=torch.float32, device=device) for _ in range(2)]
-    do_gather = world > 1 and a.gather == "root"
+    do_gather = world > 1 and a.gather == "every"
+    final_gather = world > 1 and a.gather == "final"
     comm = torch.cuda.Stream(device) if do_gather else None
-    gather_out = ([torch.empty((n_local, 4), dtype=torch.float32, device=device) for _ in range(world)]
-                  if (do_gather and rank == 0) else None)
+    stage = device if backend == "nccl" else torch.device("cpu")
+    gather_out = ([torch.empty((n_local, 4), dtype=torch.float32, device=stage) for _ in range(world)]
+                  if ((do_gather or final_gather) and rank == 0) else None)
     done_ev = [torch.cuda.Event(), torch.cuda.Event()]
     free_ev = [None, None]
     variant = _lib.PLUGIN_MEASURED
@@ -172,7 +184,7 @@ def main():
             done_ev[b].record()
             with torch.cuda.stream(comm):
                 comm.wait_event(done_ev[b])
-                dist.gather(pack_result(wo[b], pdf_s[b]), gather_out, dst=0)
+                dist.gather(pack_result(wo[b], pdf_s[b]).to(stage), gather_out, dst=0)
                 free_ev[b] = torch.cuda.Event()
                 free_ev[b].record()
 
@@ -182,19 +194,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def concat_final(k_last):
+        b = k_last & 1
+        dist.gather(pack_result(wo[b], pdf_s[b]).to(stage), gather_out, dst=0)
+
     for k in range(a.warmup):
         step(k)
+    if final_gather:
+        concat_final(max(a.warmup - 1, 0))  # also initialises the RCCL communicator outside the timed region
     fence()
     smp.set_profiling(True)
     t0 = time.perf_counter()
     for k in range(a.steps):
         step(a.warmup + k)
+    if final_gather:
+        concat_final(a.warmup + a.steps - 1)
     fence()
     dt = time.perf_counter() - t0
     n_launch, kern_ms = smp.profile_read()
     smp.set_profiling(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=stage)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -231,7 +251,8 @@ def main():
             "config": {"workload": a.workload, "material": material, "domain": domain,
                        "queries_per_gpu": n_local, "global_queries": n_total, "euler_steps": T,
                        "api": "plugin-level sample()+pdf() (warp + guards fused), in-kernel Philox RNG",
-                       "parallelism": f"query-sharded x{world}" + (", RCCL gather-to-root overlapped" if do_gather else ""),
+                       "parallelism": f"query-sharded x{world}" + (", RCCL gather-to-root every step (overlapped)" if do_gather else
+                                                                   ", RCCL gather-to-root of the final results" if final_gather else ""),
                        "precision": smp.precision},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": traffic,

@@ -37,6 +37,10 @@
 
 #include "bsdfd.h"
 
+#ifndef BSDFD_ABL
+#define BSDFD_ABL 0  // ablation bitmask for timing experiments under tools/ (always 0 in the product)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -107,6 +111,15 @@ __device__ __forceinline__ float silu(float z) {  // base net: unscaled
 
 // hi/lo split of an fp32 value into two fp16-representable fp32 values (see header comment)
 __device__ __forceinline__ float hi_part(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFFE000u); }
+
+// round-to-nearest variant (hi = fp16(x), lo = fp16(x - hi)): |lo| <= 2^-12 |x|, total error 2^-24 |x|,
+// i.e. fp32-class; used once per query in the prologue where the few extra conversions are free.
+__device__ __forceinline__ void split_pack_rne(const float (&x)[4], f16x2& h01, f16x2& h23, f16x2& l01, f16x2& l23) {
+    h01 = (f16x2){(_Float16)x[0], (_Float16)x[1]};
+    h23 = (f16x2){(_Float16)x[2], (_Float16)x[3]};
+    l01 = (f16x2){(_Float16)(x[0] - (float)h01[0]), (_Float16)(x[1] - (float)h01[1])};
+    l23 = (f16x2){(_Float16)(x[2] - (float)h23[0]), (_Float16)(x[3] - (float)h23[1])};
+}
 
 union Frag {  // one MFMA B fragment: the lane's 8 K-values of a chunk
     f16x8 v;
@@ -315,9 +328,13 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
         float pe[PE_BANDS];
 #pragma unroll
         for (int b = 0; b < PE_BANDS; ++b) {
+#if (BSDFD_ABL & 1)
+            pe[b] = ysel * (float)(1 << b);
+#else
             float sv, cv;
             sincosf(ysel * (float)(1 << b), &sv, &cv);
             pe[b] = (g >> 1) ? cv : sv;
+#endif
         }
         const float yslab = g == 0 ? y0 : (g == 1 ? y1 : 0.0f);
 
@@ -325,9 +342,13 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
         // PE_3 -> 16 (SiLU) -> 4, once per query
         f32x4 cacc[NM];
         f32x4 bo;
-        // fp32 MFMA (exact FMA chains) in every precision mode: this term enters z1 of ALL T steps, so
-        // its rounding error is systematic, not random — an fp16-split version (kept below) doubled
-        // the p99 pdf error for no measurable time saving (12 + 8 K=4 MFMAs once per query).
+        // PREC_F32: exact fp32 MFMA chains.  fp16 modes: one K=32 fp16 MFMA per 16 units with
+        // round-to-nearest hi/lo splits of both operands (fp32-class accuracy: this term enters z1
+        // of ALL T steps, so its rounding error is systematic — a truncation split here doubled the
+        // p99 pdf error); 11 MFMAs of 16 cycles instead of 20 dependent K=4 fp32 MFMAs of 32-40.
+        // (measured: the fp16 prologue saves ~12 us per 1 Mi queries, 2 % at T=8, but raises the p99
+        //  pdf error from 1.8e-5 to 2.9e-5 — the MFMA's fp16 adder tree is not an fp32 FMA chain — so
+        //  the exact fp32 form stays the default; parity is the first gate.)
         constexpr bool PROLOGUE_F32 = true;
         if (PROLOGUE_F32 || PREC == BSDFD_PREC_F32) {
 #pragma unroll
@@ -336,6 +357,9 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 #pragma unroll
                 for (int s = 0; s < PE_BANDS; ++s) a = mfma4(Lwc[(m * PE_SLABS + s) * 64 + lane], pe[s], a);
                 cacc[m] = mfma4(Lwc[(m * PE_SLABS + PE_BANDS) * 64 + lane], yslab, a);
+#if (BSDFD_ABL & 2)
+                cacc[m] = zero4 + pe[0];
+#endif
             }
             f32x4 bz = *reinterpret_cast<const f32x4*>(Lbb1 + lane * 4);
 #pragma unroll
@@ -345,6 +369,9 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             bo = *reinterpret_cast<const f32x4*>(Lbb2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) bo = mfma4(w2[r], silu(bz[r]), bo);
+#if (BSDFD_ABL & 4)
+            bo = zero4 + pe[1];
+#endif
         } else {
             // one K=32 fp16 fragment holds the lane's 5 band values + its raw coordinate:
             // k = (g, j): j < 5 -> band j, j = 5 -> y slab, j = 6,7 -> 0; split hi + lo
@@ -352,8 +379,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             {
                 const float v0[4] = {pe[0], pe[1], pe[2], pe[3]};
                 const float v1[4] = {pe[4], yslab, 0.0f, 0.0f};
-                split_pack<true>(v0, ph.p[0], ph.p[1], pl.p[0], pl.p[1]);
-                split_pack<true>(v1, ph.p[2], ph.p[3], pl.p[2], pl.p[3]);
+                split_pack_rne(v0, ph.p[0], ph.p[1], pl.p[0], pl.p[1]);
+                split_pack_rne(v1, ph.p[2], ph.p[3], pl.p[2], pl.p[3]);
             }
             const f16x8* Lwc16 = reinterpret_cast<const f16x8*>(smem + p.L.wc16);
             const f16x8* Lwc16l = reinterpret_cast<const f16x8*>(smem + p.L.wc16_lo);
@@ -375,7 +402,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             Frag bq;
             {
                 const float hv[4] = {silu(bz[0]), silu(bz[1]), silu(bz[2]), silu(bz[3])};
-                split_pack<true>(hv, bq.p[0], bq.p[1], bq.p[2], bq.p[3]);
+                split_pack_rne(hv, bq.p[0], bq.p[1], bq.p[2], bq.p[3]);
             }
             bo = *reinterpret_cast<const f32x4*>(Lbb2);
             bo = mfma16(*reinterpret_cast<const f16x8*>(smem + p.L.bw2_16a + lane * 16), bq.v, bo);
@@ -418,7 +445,11 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             }
         };
         float p0 = 1.0f;
+#if (BSDFD_ABL & 8)
+        if (p.op == OP_SAMPLE) p0 = bo[0];
+#else
         if (p.op == OP_SAMPLE) p0 = base_pdf(x0, x1);
+#endif
 
         // ---------------- T explicit Euler steps ---------------------------------------------------
         float acc = 1.0f;
