@@ -582,16 +582,20 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                                 if (JAC) { a0[mo] = mfma16(wh[mo], b0h[kc].v, a0[mo]); a1[mo] = mfma16(wh[mo], b1h[kc].v, a1[mo]); }
                             }
                             if (SPLIT) {
+#if !(BSDFD_ABL & 32)  // ablation: drop W_hi * x_lo  (p99 pdf error 1.8e-5 -> 3e-3 .. 1e-1)
 #pragma unroll
                                 for (int mo = 0; mo < NM; ++mo) {
                                     a[mo] = mfma16(wh[mo], bl[kc].v, a[mo]);
                                     if (JAC) { a0[mo] = mfma16(wh[mo], b0l[kc].v, a0[mo]); a1[mo] = mfma16(wh[mo], b1l[kc].v, a1[mo]); }
                                 }
+#endif
+#if !(BSDFD_ABL & 16)  // ablation: drop W_lo * x_hi  (p99 pdf error 1.8e-5 -> 2e-3 .. 7e-2)
 #pragma unroll
                                 for (int mo = 0; mo < NM; ++mo) {
                                     a[mo] = mfma16(wl[mo], bh[kc].v, a[mo]);
                                     if (JAC) { a0[mo] = mfma16(wl[mo], b0h[kc].v, a0[mo]); a1[mo] = mfma16(wl[mo], b1h[kc].v, a1[mo]); }
                                 }
+#endif
                             }
                         }
 #pragma unroll
