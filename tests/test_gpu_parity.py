@@ -257,3 +257,70 @@ def test_error_paths():
         s.network_sampling(wi, None, T=0)
     with pytest.raises(RuntimeError):
         s.plugin_sample(torch.zeros(4, 3, device=_dev()), None, variant=1)  # full sphere on a disk handle
+
+
+@pytest.mark.parametrize("raw_kappa", [-8.0, -0.5, 3.70, 3.80, 25.0, 400.0])
+def test_base_density_kappa_branches_and_von_mises_sampler(raw_kappa):
+    """Crafted weights: base output = its bias (constant loc/log_scale/mu/kappa_raw) and a zero
+    output layer (identity flow), so pdf == base density and samples == base draws.  Sweeps kappa
+    across softplus' threshold-free range and log I0's 3.75 polynomial switch (model.py:294-317,
+    torch von_mises._log_modified_bessel_fn), incl. the tiny-kappa proposal (fp64 in-kernel)."""
+    import copy
+    from scipy import stats
+    g, fw = load_case("aniso_miro_7_rgb_spherical")
+    fz = copy.deepcopy(fw)
+    fz.w_out = np.zeros_like(fw.w_out)
+    fz.base_w2 = np.zeros_like(fw.base_w2)
+    fz.base_b2 = np.array([0.7, -1.2, 0.4, raw_kappa], np.float32)
+    s = _sampler(fz, "split3")
+    orc = O.Oracle(fz)
+    n = 1 << 16
+    wi = np.tile(g["wi"][:1], (n, 1))
+    rng = np.random.default_rng(3)
+    x = np.stack([rng.normal(0.7, 0.4, n), rng.uniform(-np.pi, np.pi, n)], 1).astype(np.float32)
+    p = s.network_pdf(_t(x), _t(wi), T=2).cpu().numpy().astype(np.float64)
+    po = np.exp(orc.base_log_prob(x, wi))
+    ok = po > 1e-8 * po.max()
+    assert np.percentile(_rel(p, po)[ok], 99) < 2e-5 + 3e-7 * max(1.0, np.log1p(np.exp(raw_kappa)))
+    xs, ps = s.network_sampling(_t(wi), None, T=2, seed=11)
+    xs = xs.cpu().numpy().astype(np.float64)
+    mu, kappa = orc.base_von_mises_params(wi[:1])
+    assert np.all(np.abs(xs[:, 1]) <= np.pi + 1e-5)
+    d = np.angle(np.exp(1j * (xs[:, 1] - mu[0])))
+    assert stats.kstest(d, stats.vonmises(kappa[0]).cdf).pvalue > 1e-4
+    sd = np.exp(-1.2) + 1e-3
+    assert stats.kstest((xs[:, 0] - 0.7) / sd, "norm").pvalue > 1e-4
+    pso = np.exp(orc.base_log_prob(xs, wi))
+    ok = pso > 1e-8 * pso.max()
+    assert np.percentile(_rel(ps.cpu().numpy(), pso)[ok], 99) < 1e-4
+
+
+def test_guards_spherical_pole_and_horizon():
+    """sin(theta_o) <= 5e-5 and cos(theta_o) <= 0 guards of brdf_measured_spherical.py:79-80,134 with
+    crafted states: identity flow (zero output layer) returns x0 itself."""
+    import copy
+    from bsdf_diffusion_sampling_amd import _lib
+    g, fw = load_case("aniso_miro_7_rgb_spherical")
+    fz = copy.deepcopy(fw)
+    fz.w_out = np.zeros_like(fw.w_out)
+    fz.base_w2 = np.zeros_like(fw.base_w2)           # a broad, constant base density: nothing underflows
+    fz.base_b2 = np.array([1.0, 0.5, 0.0, 0.0], np.float32)
+    s = _sampler(fz, "split3")
+    wi3 = _dir(np.full(8, 0.6), np.linspace(-3, 3, 8))
+    x0 = np.array([[1e-5, 0.3], [4.9e-5, 1.0], [6e-5, 1.0], [1.0, 2.0], [1.5707, -1.0], [1.5709, 0.5],
+                   [2.5, 0.1], [3.14159, 0.0]], np.float32)
+    wo, pdf = s.plugin_sample(_t(wi3), _t(x0), T=4)
+    wo, pdf = wo.cpu().numpy(), pdf.cpu().numpy()
+    assert np.all(pdf[[0, 1]] == 0) and pdf[2] != 0 and pdf[3] != 0      # sin guard
+    assert pdf[4] != 0 and np.all(pdf[[5, 6, 7]] == 0)                     # cos guard (hemisphere)
+    assert np.allclose(wo[3], [np.cos(2.0) * np.sin(1.0), np.sin(2.0) * np.sin(1.0), np.cos(1.0)], atol=1e-6)
+    wo_f, pdf_f = s.plugin_sample(_t(wi3), _t(x0), T=4, variant=_lib.PLUGIN_FULLSPHERE)
+    pdf_f = pdf_f.cpu().numpy()
+    assert np.all(pdf_f[[0, 1]] == 0) and np.all(pdf_f[[2, 3, 4, 5, 6]] != 0)  # no cos guard on the full sphere
+    assert np.isfinite(pdf_f).all()
+    # pdf(): lanes with cos(theta_i) <= 0 or cos(theta_o) <= 0 are zero for the measured variant only
+    wo3 = _dir(np.array([0.5, 2.0, 0.5, 0.5]), np.zeros(4))
+    wi4 = _dir(np.array([0.5, 0.5, 2.0, 0.5]), np.ones(4))
+    pm = s.plugin_pdf(_t(wi4), _t(wo3), T=4).cpu().numpy()
+    pf = s.plugin_pdf(_t(wi4), _t(wo3), T=4, variant=_lib.PLUGIN_FULLSPHERE).cpu().numpy()
+    assert pm[0] != 0 and pm[1] == 0 and pm[2] == 0 and np.all(pf != 0)
