@@ -324,3 +324,20 @@ def test_guards_spherical_pole_and_horizon():
     pm = s.plugin_pdf(_t(wi4), _t(wo3), T=4).cpu().numpy()
     pf = s.plugin_pdf(_t(wi4), _t(wo3), T=4, variant=_lib.PLUGIN_FULLSPHERE).cpu().numpy()
     assert pm[0] != 0 and pm[1] == 0 and pm[2] == 0 and np.all(pf != 0)
+
+
+def test_reflow_teacher_sampler_T128_fp16_class():
+    """f2: the reference's only tiny-cuda-nn call site — 64-wide x 6 teacher, T = 128 Euler steps, no
+    Jacobian (learning_repo_cleanup/spherical_domain_sampling.py:147-166).  Its own accepted tolerance
+    for the fp16 FullyFusedMLP is rtol = atol = 1e-2 per network evaluation (tiny-cuda-nn/tmp.py:59);
+    over 128 steps we require the fp16 path to stay within 2e-2 of the fp64 oracle on >= 99 % of the
+    rows, and the split3 path within 1e-4 on all."""
+    g, fw = load_case("aniso_miro_7_rgb_spherical_complex")
+    n, T = 1024, 128
+    wi, x0 = g["wi"][:n], g["x0"][:n]
+    xo, _ = O.Oracle(fw).flow(x0, wi, T, reverse=False)
+    x16 = _sampler(fw, "f16").flow_samples_only(_t(wi), _t(x0), T=T).cpu().numpy()
+    xs3 = _sampler(fw, "split3").flow_samples_only(_t(wi), _t(x0), T=T).cpu().numpy()
+    e16 = np.abs(x16 - xo).max(1)
+    assert np.percentile(e16, 99) < 2e-2, np.percentile(e16, [50, 99, 100])
+    assert np.abs(xs3 - xo).max() < 1e-4, np.abs(xs3 - xo).max()
