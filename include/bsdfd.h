@@ -39,7 +39,10 @@ extern "C" {
  * base density and warps are always fp32 VALU). */
 #define BSDFD_PREC_DEFAULT 0  /* = BSDFD_PREC_SPLIT3 */
 #define BSDFD_PREC_F32 1      /* v_mfma_f32_16x16x4_f32: exact fp32 FMA chains (validation mode) */
-#define BSDFD_PREC_SPLIT3 2   /* fp16 MFMA, operands split hi+lo, 3 products, fp32 accumulate (<=1e-4 parity) */
+#define BSDFD_PREC_SPLIT3 2   /* fp16 MFMA, operands split hi+lo, 3 products, fp32 accumulate (<=1e-4 parity).
+                               * Range: hidden activations and tangents must stay below fp16's 65504 (they are
+                               * O(1..100) for the reference's nets and inputs); beyond it the result is inf/NaN,
+                               * never a silently wrong finite number. BSDFD_PREC_F32 has fp32 range. */
 #define BSDFD_PREC_F16 3      /* single fp16 MFMA pass (tcnn-class 1e-2 tolerance; reflow teacher sampling) */
 
 /* Plugin post-processing variants (which MyBSDF the call mirrors). */

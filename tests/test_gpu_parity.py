@@ -341,3 +341,24 @@ def test_reflow_teacher_sampler_T128_fp16_class():
     e16 = np.abs(x16 - xo).max(1)
     assert np.percentile(e16, 99) < 2e-2, np.percentile(e16, [50, 99, 100])
     assert np.abs(xs3 - xo).max() < 1e-4, np.abs(xs3 - xo).max()
+
+
+def test_extreme_inputs_do_not_crash_and_fail_loudly():
+    """Absurd states (|x0| = 1e4 .. 1e30, NaN): the fp32 reference overflows its own exp()/products; the
+    split-fp16 path additionally leaves fp16 range.  Required: no fault, the neighbouring queries of the
+    same 16-query tile are untouched, and an out-of-range query reports a non-finite or zero pdf rather
+    than a plausible finite one."""
+    g, fw = load_case("chm_orange_rgb_disk")
+    s = _sampler(fw, "split3")
+    wi, x0 = g["wi"][:64].copy(), g["x0"][:64].copy()
+    ref_x, ref_p = s.network_sampling(_t(wi), _t(x0), T=4)
+    bad = x0.copy()
+    bad[3] = [1e4, -1e4]
+    bad[17] = [1e30, 1e30]
+    bad[40] = [np.nan, 0.1]
+    x, p = s.network_sampling(_t(wi), _t(bad), T=4)
+    keep = np.ones(64, bool)
+    keep[[3, 17, 40]] = False
+    assert torch.equal(x[keep], ref_x[keep]) and torch.equal(p[keep], ref_p[keep])
+    pb = p.cpu().numpy()[[3, 17, 40]]
+    assert np.all(~np.isfinite(pb) | (pb == 0))
