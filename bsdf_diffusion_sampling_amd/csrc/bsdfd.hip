@@ -266,6 +266,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 
     const bool reverse = (p.op == OP_PDF);
     const double invT_d = 1.0 / (double)p.T;
+    const bool t_pow2 = (p.T & (p.T - 1)) == 0;
     const float invT = (float)invT_d;
     const float cstep = reverse ? -invT : invT;
     const long long ntiles = (p.N + 15) / 16;
@@ -456,8 +457,14 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
         for (int t = 0; t < p.T; ++t) {
             // alpha = float32(t/T) resp. float32(1 - t/T) as torch forms them (python double, then
             // cast); t * (1/T) in fp64 differs from t/T by < 1 ulp(fp64), invisible after the cast.
-            const double tf = (double)t * invT_d;
-            const float alpha = (float)(reverse ? 1.0 - tf : tf);
+            float alpha;
+            if (t_pow2) {  // t/T and 1 - t/T are exact in fp32 when T is a power of two: skip the fp64 ops
+                const float tf = (float)t * invT;
+                alpha = reverse ? 1.0f - tf : tf;
+            } else {
+                const double tf = (double)t * invT_d;
+                alpha = (float)(reverse ? 1.0 - tf : tf);
+            }
             f32x4 z[NM], zt0[NM], zt1[NM];
             if (DOMAIN == BSDFD_DOMAIN_DISK) {
                 const float bs = sel4(g, x0, x1, alpha, 0.0f);
@@ -628,7 +635,9 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                 const float j10 = cstep * d0[1];
                 const float j11 = 1.0f + cstep * d1[1];
                 const float det = j00 * j11 - j01 * j10;
-                if (reverse) acc *= det; else acc /= det;
+                // forward: the reference divides (tmp_J /= J); v_rcp_f32 (1 ulp) * acc differs from the
+                // IEEE quotient by <= 2 ulp, far below the fp32 noise of det itself
+                if (reverse) acc *= det; else acc *= __builtin_amdgcn_rcpf(det);
             }
             x0 += cstep * v[0];
             x1 += cstep * v[1];
