@@ -61,7 +61,6 @@ enum { IO_OPERATOR = 0, IO_PLUGIN = 1, IO_PLUGIN_FULLSPHERE = 2 };
 
 struct ImgLayout {  // byte offsets into the weight image (identical in global memory and LDS)
     int win, wc, wh, wh_lo, wo, bw1, bb1, bw2, bb2, total;
-    int wc16, wc16_lo, bw1_16, bw1_16_lo, bw2_16a, bw2_16b;  // fp16 A-fragments of the per-query prologue
 };
 
 struct KParams {
@@ -111,15 +110,6 @@ __device__ __forceinline__ float silu(float z) {  // base net: unscaled
 
 // hi/lo split of an fp32 value into two fp16-representable fp32 values (see header comment)
 __device__ __forceinline__ float hi_part(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFFE000u); }
-
-// round-to-nearest variant (hi = fp16(x), lo = fp16(x - hi)): |lo| <= 2^-12 |x|, total error 2^-24 |x|,
-// i.e. fp32-class; used once per query in the prologue where the few extra conversions are free.
-__device__ __forceinline__ void split_pack_rne(const float (&x)[4], f16x2& h01, f16x2& h23, f16x2& l01, f16x2& l23) {
-    h01 = (f16x2){(_Float16)x[0], (_Float16)x[1]};
-    h23 = (f16x2){(_Float16)x[2], (_Float16)x[3]};
-    l01 = (f16x2){(_Float16)(x[0] - (float)h01[0]), (_Float16)(x[1] - (float)h01[1])};
-    l23 = (f16x2){(_Float16)(x[2] - (float)h23[0]), (_Float16)(x[3] - (float)h23[1])};
-}
 
 union Frag {  // one MFMA B fragment: the lane's 8 K-values of a chunk
     f16x8 v;
@@ -343,72 +333,38 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
         // PE_3 -> 16 (SiLU) -> 4, once per query
         f32x4 cacc[NM];
         f32x4 bo;
-        // PREC_F32: exact fp32 MFMA chains.  fp16 modes: one K=32 fp16 MFMA per 16 units with
-        // round-to-nearest hi/lo splits of both operands (fp32-class accuracy: this term enters z1
-        // of ALL T steps, so its rounding error is systematic — a truncation split here doubled the
-        // p99 pdf error); 11 MFMAs of 16 cycles instead of 20 dependent K=4 fp32 MFMAs of 32-40.
-        // (measured: the fp16 prologue saves ~12 us per 1 Mi queries, 2 % at T=8, but raises the p99
-        //  pdf error from 1.8e-5 to 2.9e-5 — the MFMA's fp16 adder tree is not an fp32 FMA chain — so
-        //  the exact fp32 form stays the default; parity is the first gate.)
-        constexpr bool PROLOGUE_F32 = true;
-        if (PROLOGUE_F32 || PREC == BSDFD_PREC_F32) {
+        // c = W1[:, PE] PE(omega_i): exact fp32 MFMA chains (K = 4 slabs) in EVERY precision mode — this
+        // term enters z1 of all T steps, so its rounding error is systematic: an fp16-split version
+        // saved ~12 us per 1 Mi queries but raised the p99 pdf error from 1.8e-5 to 2.9e-5 (the MFMA's
+        // fp16 adder tree is not an fp32 FMA chain).  The NM chains (and the base net's) are issued
+        // slab-major so that consecutive MFMAs are independent (40-cycle dependent latency).
+        // The base net (PE_3 -> 16 -> 4) also stays exact fp32: its outputs (loc, log sigma) are divided
+        // by sigma ~ 1e-2 for peaked materials, so an fp16-split evaluation (measured) raised the p99
+        // pdf error of aniso_miro_7 from 1.8e-5 to 2.9e-5.
+        f32x4 bz = *reinterpret_cast<const f32x4*>(Lbb1 + lane * 4);
 #pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                f32x4 a = zero4;
+        for (int m = 0; m < NM; ++m) cacc[m] = zero4;
 #pragma unroll
-                for (int s = 0; s < PE_BANDS; ++s) a = mfma4(Lwc[(m * PE_SLABS + s) * 64 + lane], pe[s], a);
-                cacc[m] = mfma4(Lwc[(m * PE_SLABS + PE_BANDS) * 64 + lane], yslab, a);
+        for (int s = 0; s < PE_SLABS; ++s) {
+            const float b = s < PE_BANDS ? pe[s < PE_BANDS ? s : 0] : yslab;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) cacc[m] = mfma4(Lwc[(m * PE_SLABS + s) * 64 + lane], b, cacc[m]);
+            if (s < BASE_PE_BANDS) bz = mfma4(Lbw1[s * 64 + lane], b, bz);
+            if (s == PE_BANDS) bz = mfma4(Lbw1[BASE_PE_BANDS * 64 + lane], b, bz);
+        }
 #if (BSDFD_ABL & 2)
-                cacc[m] = zero4 + pe[0];
-#endif
-            }
-            f32x4 bz = *reinterpret_cast<const f32x4*>(Lbb1 + lane * 4);
 #pragma unroll
-            for (int s = 0; s < BASE_PE_BANDS; ++s) bz = mfma4(Lbw1[s * 64 + lane], pe[s], bz);
-            bz = mfma4(Lbw1[BASE_PE_BANDS * 64 + lane], yslab, bz);
+        for (int m = 0; m < NM; ++m) cacc[m] = zero4 + pe[0];
+#endif
+        {
             const f32x4 w2 = *reinterpret_cast<const f32x4*>(Lbw2 + lane * 4);
             bo = *reinterpret_cast<const f32x4*>(Lbb2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) bo = mfma4(w2[r], silu(bz[r]), bo);
-#if (BSDFD_ABL & 4)
-            bo = zero4 + pe[1];
-#endif
-        } else {
-            // one K=32 fp16 fragment holds the lane's 5 band values + its raw coordinate:
-            // k = (g, j): j < 5 -> band j, j = 5 -> y slab, j = 6,7 -> 0; split hi + lo
-            Frag ph, pl;
-            {
-                const float v0[4] = {pe[0], pe[1], pe[2], pe[3]};
-                const float v1[4] = {pe[4], yslab, 0.0f, 0.0f};
-                split_pack_rne(v0, ph.p[0], ph.p[1], pl.p[0], pl.p[1]);
-                split_pack_rne(v1, ph.p[2], ph.p[3], pl.p[2], pl.p[3]);
-            }
-            const f16x8* Lwc16 = reinterpret_cast<const f16x8*>(smem + p.L.wc16);
-            const f16x8* Lwc16l = reinterpret_cast<const f16x8*>(smem + p.L.wc16_lo);
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                const f16x8 ah = Lwc16[m * 64 + lane], al = Lwc16l[m * 64 + lane];
-                f32x4 a = mfma16(ah, ph.v, zero4);
-                a = mfma16(ah, pl.v, a);
-                cacc[m] = mfma16(al, ph.v, a);
-            }
-            const f16x8 b1h = *reinterpret_cast<const f16x8*>(smem + p.L.bw1_16 + lane * 16);
-            const f16x8 b1l = *reinterpret_cast<const f16x8*>(smem + p.L.bw1_16_lo + lane * 16);
-            f32x4 bz = *reinterpret_cast<const f32x4*>(Lbb1 + lane * 4);
-            bz = mfma16(b1h, ph.v, bz);
-            bz = mfma16(b1h, pl.v, bz);
-            bz = mfma16(b1l, ph.v, bz);
-            // output layer, K = 16 hidden units: B = [h hi (j<4) | h lo (j>=4)], A = [W2 hi | W2 hi]
-            // gives hi*hi + hi*lo in one MFMA; the second, A = [W2 lo | 0], adds lo*hi.
-            Frag bq;
-            {
-                const float hv[4] = {silu(bz[0]), silu(bz[1]), silu(bz[2]), silu(bz[3])};
-                split_pack_rne(hv, bq.p[0], bq.p[1], bq.p[2], bq.p[3]);
-            }
-            bo = *reinterpret_cast<const f32x4*>(Lbb2);
-            bo = mfma16(*reinterpret_cast<const f16x8*>(smem + p.L.bw2_16a + lane * 16), bq.v, bo);
-            bo = mfma16(*reinterpret_cast<const f16x8*>(smem + p.L.bw2_16b + lane * 16), bq.v, bo);
         }
+#if (BSDFD_ABL & 4)
+        bo = zero4 + pe[1];
+#endif
         // bo = (loc0, loc1, ls0, ls1) disk | (loc, log_scale, mu, kappa_raw) spherical
         float kappa = 0.0f;
         if (DOMAIN == BSDFD_DOMAIN_SPHERICAL) kappa = softplus(bo[3]) + 1e-3f;
@@ -432,17 +388,21 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             }
         }
 
+        // exp() below is v_exp_f32(x * log2 e): <= 2 ulp + |x| 2^-24 from the argument scaling, the same
+        // conditioning the reference's own fp32 exp(logp) has; (x - loc) / exp(ls) is formed as
+        // (x - loc) * exp(-ls).
+        auto fexp = [](float x) -> float { return __builtin_amdgcn_exp2f(x * kLog2e); };
         auto base_pdf = [&](float a0, float a1) -> float {
             const float log2pi = 1.8378770664093453f;
             if (DOMAIN == BSDFD_DOMAIN_DISK) {  // model.py:393-398
-                const float e0 = (a0 - bo[0]) / expf(bo[2]);
-                const float e1 = (a1 - bo[1]) / expf(bo[3]);
-                return expf(-log2pi - (bo[2] + bo[3]) - 0.5f * (e0 * e0 + e1 * e1));
+                const float e0 = (a0 - bo[0]) * fexp(-bo[2]);
+                const float e1 = (a1 - bo[1]) * fexp(-bo[3]);
+                return fexp(-log2pi - (bo[2] + bo[3]) - 0.5f * (e0 * e0 + e1 * e1));
             } else {                            // model.py:308-317
-                const float e = (a0 - bo[0]) / (expf(bo[1]) + 1e-3f);
+                const float e = (a0 - bo[0]) / (fexp(bo[1]) + 1e-3f);
                 const float loggau = -0.5f * log2pi - bo[1] - 0.5f * e * e;
                 const float logvon = kappa * cosf(a1 - bo[2]) - log2pi - log_i0(kappa);
-                return expf(loggau + logvon);
+                return fexp(loggau + logvon);
             }
         };
         float p0 = 1.0f;
@@ -769,15 +729,6 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
         if (prec == BSDFD_PREC_SPLIT3) off += (NH - 1) * NM * KC * 64 * 16;
         L.wo = off; off += KC * 64 * 16;
     }
-    L.wc16 = L.wc16_lo = L.bw1_16 = L.bw1_16_lo = L.bw2_16a = L.bw2_16b = 0;
-    if (prec != BSDFD_PREC_F32) {
-        L.wc16 = off; off += NM * 64 * 16;
-        L.wc16_lo = off; off += NM * 64 * 16;
-        L.bw1_16 = off; off += 64 * 16;
-        L.bw1_16_lo = off; off += 64 * 16;
-        L.bw2_16a = off; off += 64 * 16;
-        L.bw2_16b = off; off += 64 * 16;
-    }
     L.bw1 = off; off += (BASE_PE_BANDS + 1) * 64 * 4;
     L.bb1 = off; off += 64 * 16;
     L.bw2 = off; off += 64 * 16;
@@ -808,34 +759,6 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
         }
     }
     for (int r = 0; r < 4; ++r) F(L.bb2)[r] = d.base_b2[r];
-
-    if (prec != BSDFD_PREC_F32) {
-        auto put = [&](int off_hi, int off_lo, size_t idx, float w) {
-            H(off_hi)[idx] = f32_to_f16_bits(w);
-            if (off_lo) H(off_lo)[idx] = f32_to_f16_bits(w - f16_round(w));
-        };
-        for (int l = 0; l < 64; ++l) {
-            const int g = l >> 4, i = l & 15;
-            for (int j = 0; j < 8; ++j) {
-                // K position (g, j): j < 5 band j of (dim g&1, fn g>>1); j = 5 raw coordinate; else 0
-                for (int m = 0; m < NM; ++m) {
-                    const int unit = 16 * m + i;
-                    float w = 0.0f;
-                    if (j < PE_BANDS) w = d.w_in[unit * IN + SD + 1 + 2 + 4 * j + 2 * (g >> 1) + (g & 1)];
-                    else if (j == PE_BANDS && g < 2) w = d.w_in[unit * IN + SD + 1 + g];
-                    put(L.wc16, L.wc16_lo, ((size_t)m * 64 + l) * 8 + j, w);
-                }
-                float wb = 0.0f;
-                if (j < BASE_PE_BANDS) wb = d.base_w1[i * BIN + 2 + 4 * j + 2 * (g >> 1) + (g & 1)];
-                else if (j == PE_BANDS && g < 2) wb = d.base_w1[i * BIN + g];
-                put(L.bw1_16, L.bw1_16_lo, (size_t)l * 8 + j, wb);
-                // base output layer: k = hidden unit 4g + (j&3); j < 4 pairs with h_hi, j >= 4 with h_lo
-                const float w2 = d.base_w2[(i & 3) * BASE_HIDDEN + 4 * g + (j & 3)];
-                H(L.bw2_16a)[(size_t)l * 8 + j] = f32_to_f16_bits(w2);
-                H(L.bw2_16b)[(size_t)l * 8 + j] = f32_to_f16_bits(j < 4 ? w2 - f16_round(w2) : 0.0f);
-            }
-        }
-    }
 
     if (prec == BSDFD_PREC_F32) {
         for (int layer = 0; layer < NH - 1; ++layer)
