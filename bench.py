@@ -154,6 +154,12 @@ def main():
     from bsdf_diffusion_sampling_amd.sampler import FlowSampler
     from bsdf_diffusion_sampling_amd.sharding import pack_result
 
+    if not os.path.exists(_lib.LIB_PATH):  # clean checkout: compile the HIP library (rank 0), others wait
+        if rank == 0:
+            _lib.build(verbose=True)
+        if world > 1:
+            dist.barrier()
+
     material, domain, n_local, T = WORKLOADS[a.workload]
     n_total = n_local * world
     lo = rank * n_local
