@@ -313,20 +313,41 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
         }
 
         // ---------------- positional encoding, distributed over the 4 lanes of a query -----------
-        // lane g evaluates (dim = g&1, fn = g>>1 ? cos : sin) for every band: slab b of the K=4
-        // contraction is [sin(2^b y0), sin(2^b y1), cos(2^b y0), cos(2^b y1)] = PE block b.
+        // lane g needs fn(2^b y_d) for dim d = g&1, fn = g>>1 ? cos : sin, b = 0..4: slab b of the K=4
+        // contraction is [sin(2^b y0), sin(2^b y1), cos(2^b y0), cos(2^b y1)] = PE block b.  Lanes g and
+        // g^2 (lane ^ 32) need the sin resp. cos of the SAME angles, so the sincos evaluations are
+        // shared: the lower half-wave evaluates bands 0..2, the upper half bands 3..4, and three
+        // v_permlane32_swap exchange the halves (3 sincosf per lane instead of 5).
         const float ysel = (g & 1) ? y1 : y0;
         float pe[PE_BANDS];
-#pragma unroll
-        for (int b = 0; b < PE_BANDS; ++b) {
 #if (BSDFD_ABL & 1)
-            pe[b] = ysel * (float)(1 << b);
+#pragma unroll
+        for (int b = 0; b < PE_BANDS; ++b) pe[b] = ysel * (float)(1 << b);
 #else
-            float sv, cv;
-            sincosf(ysel * (float)(1 << b), &sv, &cv);
-            pe[b] = (g >> 1) ? cv : sv;
-#endif
+        {
+            const bool upper = (g >> 1) != 0;  // lanes 32..63: want cos; evaluate bands 3, 4
+            float sv[3], cv[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) sincosf(ysel * (upper ? (float)(8 << k) : (float)(1 << k)), &sv[k], &cv[k]);
+            // swap(vdst, src): vdst[32..63] <-> src[0..31].  vdst = upper-half sin of band 3+k, src =
+            // lower-half cos of band k: afterwards the lower half finds sin(band 3+k) in `src` and
+            // the upper half finds cos(band k) in `vdst`.
+            unsigned got[3][2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(sv[k]), __float_as_uint(cv[k]), false, false);
+                got[k][0] = r[0];
+                got[k][1] = r[1];
+            }
+            // lower half (sin): bands 0..2 own sv[k]; bands 3..4 arrived in r[1] of swaps 0, 1
+            // upper half (cos): bands 3..4 own cv[0..1]; bands 0..2 arrived in r[0] of swaps 0..2
+            pe[0] = upper ? __uint_as_float(got[0][0]) : sv[0];
+            pe[1] = upper ? __uint_as_float(got[1][0]) : sv[1];
+            pe[2] = upper ? __uint_as_float(got[2][0]) : sv[2];
+            pe[3] = upper ? cv[0] : __uint_as_float(got[0][1]);
+            pe[4] = upper ? cv[1] : __uint_as_float(got[1][1]);
         }
+#endif
         const float yslab = g == 0 ? y0 : (g == 1 ? y1 : 0.0f);
 
         // conditioning part of layer 1 (constant across the Euler steps) and the base-density net
