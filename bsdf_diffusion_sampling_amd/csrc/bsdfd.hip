@@ -397,14 +397,18 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             const unsigned k0 = (unsigned)p.seed, k1 = (unsigned)(p.seed >> 32);
             unsigned u[4];
             philox4x32(k0, k1, (unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0x476175u, u);  // "Gau"
-            const float rad = sqrtf(-2.0f * logf(u01_open(u[0])));
-            float sn, cs;
-            sincospif(2.0f * u01_open(u[1]), &sn, &cs);
+            // Box-Muller on hardware transcendentals (v_log/v_sqrt/v_sin/v_cos; v_sin and v_cos take
+            // revolutions, so sin(2 pi u) needs no range reduction).  The draw is statistically, never
+            // bit-wise, comparable with torch's RNG, so ~1e-6 function error is immaterial here.
+            const float rad = __builtin_amdgcn_sqrtf(-2.0f * kLn2 * __builtin_amdgcn_logf(u01_open(u[0])));
+            const float rev = u01_open(u[1]);
+            const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
+            auto fexp0 = [](float x) -> float { return __builtin_amdgcn_exp2f(x * kLog2e); };
             if (DOMAIN == BSDFD_DOMAIN_DISK) {  // model.py:387-392
-                x0 = bo[0] + rad * cs * expf(bo[2]);
-                x1 = bo[1] + rad * sn * expf(bo[3]);
+                x0 = bo[0] + rad * cs * fexp0(bo[2]);
+                x1 = bo[1] + rad * sn * fexp0(bo[3]);
             } else {                            // model.py:298-307
-                x0 = bo[0] + rad * cs * (expf(bo[1]) + 1e-3f);
+                x0 = bo[0] + rad * cs * (fexp0(bo[1]) + 1e-3f);
                 x1 = von_mises_sample(bo[2], kappa, k0, k1, (unsigned)ctr, (unsigned)(ctr >> 32));
             }
         }
