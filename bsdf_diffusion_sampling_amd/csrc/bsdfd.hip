@@ -214,7 +214,10 @@ __device__ float von_mises_sample(float mu, float kappa, unsigned k0, unsigned k
 //   DOMAIN : BSDFD_DOMAIN_*            NM : width/16 (2 or 4)
 //   PREC   : BSDFD_PREC_F32 / SPLIT3 / F16      JAC : track the Jacobian determinant
 // ---------------------------------------------------------------------------------------------
-template <int DOMAIN, int NM, int PREC, bool JAC>
+//   NH     : number of hidden layers when known at compile time (3 disk, 4 spherical; 32-wide nets: the
+//            layer loop is then fully unrolled — no loop-carried register copies, `last` is static;
+//            measured -3..4 % per Euler step), 0 = run-time p.n_hidden (any depth).
+template <int DOMAIN, int NM, int PREC, bool JAC, int NH>
 __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     {
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
     __syncthreads();
 
     constexpr int KC = NM / 2;  // K chunks of 32 for the fp16 MFMA
+    const int n_hidden = NH ? NH : p.n_hidden;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4;
     const int q = lane & 15;
@@ -474,8 +478,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 
             f32x4 v = zero4, d0 = zero4, d1 = zero4;  // rows r=0,1: the two outputs
             if (PREC == BSDFD_PREC_F32) {
-                for (int layer = 0; layer < p.n_hidden; ++layer) {
-                    const bool last = (layer == p.n_hidden - 1);
+                for (int layer = 0; layer < n_hidden; ++layer) {
+                    const bool last = (layer == n_hidden - 1);
                     float h[NM][4], t0[NM][4], t1[NM][4];
 #pragma unroll
                     for (int m = 0; m < NM; ++m)
@@ -532,8 +536,9 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                 // with the VALU work of the next measured no faster: on gfx950 a 16x16x32 MFMA hides
                 // only ~3 VALU issues, tools/ubench/mfma_overlap.hip — MFMA and VALU time add.)
                 constexpr bool SPLIT = (PREC == BSDFD_PREC_SPLIT3);
-                for (int layer = 0; layer < p.n_hidden; ++layer) {
-                    const bool last = (layer == p.n_hidden - 1);
+#pragma unroll
+                for (int layer = 0; layer < n_hidden; ++layer) {
+                    const bool last = (layer == n_hidden - 1);
                     Frag bh[KC], bl[KC], b0h[KC], b0l[KC], b1h[KC], b1l[KC];
 #pragma unroll
                     for (int m = 0; m < NM; ++m) {
@@ -827,26 +832,31 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
     return img;
 }
 
-// kernel instantiation table
-template <int DOMAIN, int NM>
+// kernel instantiation table: (domain, width/16, precision, Jacobian) x {generic depth, the reference's depths}
+template <int DOMAIN, int NM, int NH>
 const void* kernel_ptr_prec(int prec, bool jac) {
     switch (prec) {
         case BSDFD_PREC_F32:
-            return jac ? reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F32, true>)
-                       : reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F32, false>);
+            return jac ? reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F32, true, 0>)
+                       : reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F32, false, 0>);
         case BSDFD_PREC_F16:
-            return jac ? reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F16, true>)
-                       : reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F16, false>);
+            return jac ? reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F16, true, NH>)
+                       : reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F16, false, NH>);
         default:
-            return jac ? reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_SPLIT3, true>)
-                       : reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_SPLIT3, false>);
+            return jac ? reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_SPLIT3, true, NH>)
+                       : reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_SPLIT3, false, NH>);
     }
 }
-const void* kernel_ptr(int domain, int nm, int prec, bool jac) {
-    if (domain == BSDFD_DOMAIN_DISK)
-        return nm == 2 ? kernel_ptr_prec<BSDFD_DOMAIN_DISK, 2>(prec, jac) : kernel_ptr_prec<BSDFD_DOMAIN_DISK, 4>(prec, jac);
-    return nm == 2 ? kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 2>(prec, jac)
-                   : kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 4>(prec, jac);
+const void* kernel_ptr(int domain, int nm, int n_hidden, int prec, bool jac) {
+    if (domain == BSDFD_DOMAIN_DISK) {
+        if (nm == 2) return n_hidden == 3 ? kernel_ptr_prec<BSDFD_DOMAIN_DISK, 2, 3>(prec, jac)
+                                          : kernel_ptr_prec<BSDFD_DOMAIN_DISK, 2, 0>(prec, jac);
+        return kernel_ptr_prec<BSDFD_DOMAIN_DISK, 4, 0>(prec, jac);
+    }
+    if (nm == 2) return n_hidden == 4 ? kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 2, 4>(prec, jac)
+                                      : kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 2, 0>(prec, jac);
+    // the 64-wide nets keep the run-time loop: fully unrolled, 6 layers of 64-wide fragments spill
+    return kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 4, 0>(prec, jac);
 }
 inline int threads_for(int nm) { return nm == 2 ? 256 : 512; }
 
@@ -969,7 +979,7 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
         if (e == hipSuccess) e = hipEventCreate(&h->ev1[i]);
     }
     for (int jac = 0; jac < 2 && e == hipSuccess; ++jac) {
-        h->kfun[jac] = kernel_ptr(h->domain, h->width / 16, prec, jac != 0);
+        h->kfun[jac] = kernel_ptr(h->domain, h->width / 16, h->n_hidden, prec, jac != 0);
         // dynamic LDS above the default cap needs the attribute (per function and device)
         e = hipFuncSetAttribute(h->kfun[jac], hipFuncAttributeMaxDynamicSharedMemorySize, h->L.total);
         int nb = 0;
