@@ -124,3 +124,52 @@ def test_all_shipped_weight_sets_run_and_are_sane():
             assert torch.isfinite(wo).all() and torch.isfinite(pdf).all(), stem
             assert (pdf > 0).float().mean() > 0.5, stem
             s.close()
+
+
+def test_every_shipped_material_matches_the_oracle():
+    """Accuracy sweep over all 77 plugin weight sets (27 disk, 25 spherical, 25 full-sphere bsdf_<i>):
+    flow + pdf vs the fp64 oracle on 1024 queries each, same tolerances as the golden cases."""
+    from bsdf_diffusion_sampling_amd import weights as W
+    from bsdf_diffusion_sampling_amd.sampler import FlowSampler
+    rng = np.random.default_rng(2024)
+    n = 1024
+    worst = {}
+    for dom in ("disk", "spherical"):
+        T = 4 if dom == "disk" else 8
+        for stem in W.list_shipped(dom):
+            fw = W.load(W.shipped_path(stem[: -len(dom) - 1], dom))
+            orc = O.Oracle(fw)
+            if dom == "disk":
+                r, a = 0.95 * np.sqrt(rng.random(n)), 2 * np.pi * rng.random(n)
+                cond = np.stack([r * np.cos(a), r * np.sin(a)], 1)
+                x0 = orc.base_sample(cond, rng.standard_normal((n, 2)))
+            else:
+                hi = 3.0 if stem.startswith("bsdf_") else 1.5
+                cond = np.stack([hi * rng.random(n), (2 * rng.random(n) - 1) * np.pi], 1)
+                mu, kappa = orc.base_von_mises_params(cond)
+                x0 = orc.base_sample(cond, rng.standard_normal(n), phi=rng.vonmises(mu, kappa))
+            cond32, x032 = cond.astype(np.float32), x0.astype(np.float32)
+            s = FlowSampler(fw)
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(_dev())
+            x, p = s.network_sampling(t(cond32), t(x032), T=T)
+            x, p = x.cpu().numpy().astype(np.float64), p.cpu().numpy().astype(np.float64)
+            xo, po = orc.network_sampling(cond32, x032, T)
+            _, acc = orc.flow(x032, cond32, T, reverse=False)
+            assert np.isfinite(p).all(), stem
+            ok = (np.abs(acc) > 1e-3) & (np.abs(acc) < 1e3)
+            ok &= np.abs(po) > 1e-6 * np.percentile(np.abs(po[ok]), 99)
+            rel = np.abs(p - po)[ok] / np.abs(po[ok])
+            xerr = np.abs(x - xo)[ok].max()
+            worst[stem] = (np.percentile(rel, 99), xerr)
+            assert xerr < 1e-4, (stem, xerr)
+            assert np.percentile(rel, 99) < 1e-4, (stem, np.percentile(rel, 99))
+            # reverse direction on the produced points
+            pp = s.network_pdf(t(x.astype(np.float32)), t(cond32), T=T).cpu().numpy().astype(np.float64)
+            ppo = orc.network_pdf(x.astype(np.float32), cond32, T)
+            _, accr = orc.flow(x.astype(np.float32), cond32, T, reverse=True)
+            okr = (np.abs(accr) > 1e-3) & (np.abs(accr) < 1e3)
+            okr &= np.abs(ppo) > 1e-6 * np.percentile(np.abs(ppo[okr]), 99)
+            assert np.percentile(np.abs(pp - ppo)[okr] / np.abs(ppo[okr]), 99) < 1e-4, stem
+            s.close()
+    w = max(worst.items(), key=lambda kv: kv[1][0])
+    print("worst p99 pdf rel-err:", w)
