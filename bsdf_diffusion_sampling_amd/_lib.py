@@ -23,7 +23,8 @@ PLUGIN_MEASURED, PLUGIN_FULLSPHERE = 0, 1
 EXPORTS = (
     "bsdfd_create", "bsdfd_create_from_file", "bsdfd_destroy", "bsdfd_get_info",
     "bsdfd_flops_per_query", "bsdfd_network_sampling", "bsdfd_network_pdf",
-    "bsdfd_plugin_sample", "bsdfd_plugin_pdf", "bsdfd_flow_samples_only",
+    "bsdfd_plugin_sample", "bsdfd_plugin_pdf", "bsdfd_plugin_sample_multi", "bsdfd_plugin_pdf_multi",
+    "bsdfd_flow_samples_only",
     "bsdfd_set_profiling", "bsdfd_profile_read", "bsdfd_last_kernel_ms", "bsdfd_last_error", "bsdfd_version",
 )
 
@@ -77,6 +78,8 @@ def lib():
     L.bsdfd_network_pdf.argtypes = [vp, fp, fp, i64, i32, fp, vp]
     L.bsdfd_plugin_sample.argtypes = [vp, i32, fp, fp, u64, u64, i64, i32, fp, fp, vp]
     L.bsdfd_plugin_pdf.argtypes = [vp, i32, fp, fp, i64, i32, fp, vp]
+    L.bsdfd_plugin_sample_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, u64, u64, i32, fp, fp, vp]
+    L.bsdfd_plugin_pdf_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, i32, fp, vp]
     L.bsdfd_flow_samples_only.argtypes = [vp, fp, fp, i64, i32, fp, vp]
     L.bsdfd_set_profiling.argtypes = [vp, i32]
     L.bsdfd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]

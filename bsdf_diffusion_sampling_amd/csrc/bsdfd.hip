@@ -57,6 +57,7 @@ constexpr int PE_SLABS = PE_BANDS + 1;  // K=4 slabs: one per band (sin/cos x 2 
 // hi*hi + hi*lo + lo*hi accumulate into ONE fp32 accumulator.
 
 enum { OP_SAMPLE = 0, OP_PDF = 1, OP_SAMPLES_ONLY = 2 };
+constexpr int MAX_SEG = 64;  // materials per segmented launch (the descriptors travel in the kernel arguments)
 enum { IO_OPERATOR = 0, IO_PLUGIN = 1, IO_PLUGIN_FULLSPHERE = 2 };
 
 struct ImgLayout {  // byte offsets into the weight image (identical in global memory and LDS)
@@ -76,6 +77,15 @@ struct KParams {
     int op;
     int io;
     unsigned long long seed, offset;
+    // multi-material ("segmented") launch: the query arrays hold nseg contiguous buckets, one per
+    // material; workgroups [blk_begin, blk_end) of the grid serve bucket [q_begin, q_end) with that
+    // material's weight image.  nseg == 0: ordinary single-material launch over [0, N).
+    int nseg;
+    struct Seg {
+        const char* img;
+        long long q_begin, q_end;
+        int blk_begin, blk_end;
+    } seg[MAX_SEG];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -220,8 +230,22 @@ __device__ float von_mises_sample(float mu, float kappa, unsigned k0, unsigned k
 template <int DOMAIN, int NM, int PREC, bool JAC, int NH>
 __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // this workgroup's share of the work: the whole batch, or one material's bucket
+    const char* img = p.img;
+    long long q_begin = 0, q_end = p.N;
+    int blk = blockIdx.x, nblk = gridDim.x;
+    if (p.nseg > 0) {
+        int sidx = 0;
+        for (int i = 1; i < p.nseg; ++i)
+            if ((int)blockIdx.x >= p.seg[i].blk_begin) sidx = i;
+        img = p.seg[sidx].img;
+        q_begin = p.seg[sidx].q_begin;
+        q_end = p.seg[sidx].q_end;
+        blk = blockIdx.x - p.seg[sidx].blk_begin;
+        nblk = p.seg[sidx].blk_end - p.seg[sidx].blk_begin;
+    }
     {
-        const uint4* src = reinterpret_cast<const uint4*>(p.img);
+        const uint4* src = reinterpret_cast<const uint4*>(img);
         uint4* dst = reinterpret_cast<uint4*>(smem);
         for (int i = threadIdx.x; i < p.L.total / 16; i += blockDim.x) dst[i] = src[i];
     }
@@ -263,7 +287,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
     const bool t_pow2 = (p.T & (p.T - 1)) == 0;
     const float invT = (float)invT_d;
     const float cstep = reverse ? -invT : invT;
-    const long long ntiles = (p.N + 15) / 16;
+    const long long ntiles = (q_end - q_begin + 15) / 16;
 
     // Tile -> wave map: a workgroup takes CHUNKS of 8 x waves_per_block consecutive tiles, chunks
     // round-robin over the grid.  Consecutive tiles of a chunk stay on one CU (one XCD's L2), so the
@@ -271,13 +295,13 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
     // tiles measured +35 % HBM reads), while the round-robin of chunks keeps the dynamic balance.
     const long long chunk = 8LL * waves_per_block;
     for (long long it = 0;; ++it) {
-        const long long chunk_base = ((it >> 3) * gridDim.x + blockIdx.x) * chunk;
+        const long long chunk_base = ((it >> 3) * nblk + blk) * chunk;
         if (chunk_base >= ntiles) break;
         const long long tile = chunk_base + (it & 7) * waves_per_block + wave;
         if (tile >= ntiles) continue;
-        const long long qi_raw = tile * 16 + q;
-        const bool valid = qi_raw < p.N;
-        const long long qi = valid ? qi_raw : p.N - 1;
+        const long long qi_raw = q_begin + tile * 16 + q;
+        const bool valid = qi_raw < q_end;
+        const long long qi = valid ? qi_raw : q_end - 1;
 
         // ---------------- inputs: condition (y0,y1) and, for pdf, the outgoing point -------------
         float y0, y1, wi_z = 1.0f;
@@ -873,8 +897,13 @@ hipError_t harvest(bsdfd_handle h, int slot) {
     return hipSuccess;
 }
 
+struct SegHost {
+    bsdfd_handle h;
+    long long q_begin, q_end;
+};
+
 int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, uint64_t seed, uint64_t offset,
-        int64_t N, int T, float* out_x, float* out_pdf, void* stream) {
+        int64_t N, int T, float* out_x, float* out_pdf, void* stream, const std::vector<SegHost>* segs = nullptr) {
     if (!h) return fail(BSDFD_EINVAL, "null handle");
     if (N < 0) return fail(BSDFD_EINVAL, "N must be >= 0");
     if (T < 1 || T > 4096) return fail(BSDFD_EINVAL, "T must be in [1, 4096]");
@@ -894,27 +923,54 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     kp.img = h->d_img; kp.L = h->L;
     kp.in_a = in_a; kp.in_b = in_b; kp.out_x = out_x; kp.out_pdf = out_pdf;
     kp.N = N; kp.T = T; kp.n_hidden = h->n_hidden; kp.op = op; kp.io = io; kp.seed = seed; kp.offset = offset;
+    kp.nseg = 0;
 
     const int NM = h->width / 16;
     const int threads = threads_for(NM);
     const int waves = threads / 64;
-    const long long ntiles = (N + 15) / 16;
-    const long long want = (ntiles + waves - 1) / waves;
-    // persistent grid: exactly the resident capacity (blocks per CU from the occupancy query of the
-    // instantiated kernel: VGPR- or LDS-limited), each wave then walks its share of the tiles
-    const bool jac_ = op != OP_SAMPLES_ONLY;
-    int per_cu = h->per_cu[jac_ ? 1 : 0];
+    // grid: 4 rounds of the resident capacity (blocks per CU from the occupancy query of the
+    // instantiated kernel: VGPR- or LDS-limited); block-granular dynamic balancing measured ~4 %
+    // faster than an exactly-resident persistent grid (tools/tscan.py sweep)
+    const bool jac = op != OP_SAMPLES_ONLY;
+    int per_cu = h->per_cu[jac ? 1 : 0];
     if (per_cu < 1) per_cu = 1;
     if (const char* ov = std::getenv("BSDFD_BLOCKS_PER_CU")) {  // tuning knob (tools/tscan.py)
         const int v = std::atoi(ov);
         if (v > 0) per_cu = v;
     }
-    // 4 rounds of resident blocks: block-granular dynamic balancing measured ~4 % faster than an
-    // exactly-resident persistent grid (tools/tscan.py sweep)
     const long long cap = (long long)h->num_cu * per_cu * 4;
-    dim3 grid((unsigned)(want < cap ? want : cap)), block(threads);
+    long long nblocks;
+    if (!segs) {
+        const long long ntiles = (N + 15) / 16;
+        const long long want = (ntiles + waves - 1) / waves;
+        nblocks = want < cap ? want : cap;
+    } else {
+        // workgroups are dealt to the buckets in proportion to their sizes (at least one each)
+        long long total_want = 0;
+        std::vector<long long> want(segs->size());
+        for (size_t i = 0; i < segs->size(); ++i) {
+            const long long nt = ((*segs)[i].q_end - (*segs)[i].q_begin + 15) / 16;
+            want[i] = (nt + waves - 1) / waves;
+            total_want += want[i];
+        }
+        const double scale = total_want > cap ? (double)cap / (double)total_want : 1.0;
+        int b = 0;
+        for (size_t i = 0; i < segs->size(); ++i) {
+            long long nb = (long long)(want[i] * scale);
+            if (nb < 1) nb = 1;
+            if (nb > want[i]) nb = want[i];
+            KParams::Seg& sg = kp.seg[kp.nseg++];
+            sg.img = (*segs)[i].h->d_img;
+            sg.q_begin = (*segs)[i].q_begin;
+            sg.q_end = (*segs)[i].q_end;
+            sg.blk_begin = b;
+            b += (int)nb;
+            sg.blk_end = b;
+        }
+        nblocks = b;
+    }
+    dim3 grid((unsigned)nblocks), block(threads);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const bool jac = op != OP_SAMPLES_ONLY;
     int slot = -1;
     if (h->profiling) {
         slot = (int)(h->n_rec % bsdfd_ctx::RING);
@@ -931,6 +987,34 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
         h->n_rec++;
     }
     return BSDFD_OK;
+}
+
+// multi-material launch: all handles must share the kernel signature (domain, width, depth, precision)
+int run_multi(const bsdfd_handle* hs, int n, const int64_t* seg_end, int op, int io, const float* in_a,
+              const float* in_b, uint64_t seed, uint64_t offset, int T, float* out_x, float* out_pdf, void* stream) {
+    if (!hs || !seg_end || n < 1) return fail(BSDFD_EINVAL, "need at least one handle and its segment end");
+    for (int i = 0; i < n; ++i) {
+        if (!hs[i]) return fail(BSDFD_EINVAL, "null handle in the table");
+        if (hs[i]->domain != hs[0]->domain || hs[i]->width != hs[0]->width || hs[i]->n_hidden != hs[0]->n_hidden ||
+            hs[i]->precision != hs[0]->precision || hs[i]->device != hs[0]->device)
+            return fail(BSDFD_EINVAL, "handles of one multi-material launch must share domain, width, depth, "
+                                      "precision and device");
+        if (seg_end[i] < (i ? seg_end[i - 1] : 0)) return fail(BSDFD_EINVAL, "segment ends must be non-decreasing");
+    }
+    const int64_t N = seg_end[n - 1];
+    if (N == 0) return BSDFD_OK;
+    // chunks of MAX_SEG non-empty buckets per launch
+    std::vector<SegHost> segs;
+    int rc = BSDFD_OK;
+    for (int i = 0; i < n && rc == BSDFD_OK; ++i) {
+        const long long b = i ? seg_end[i - 1] : 0, e = seg_end[i];
+        if (e > b) segs.push_back({hs[i], b, e});
+        if ((int)segs.size() == MAX_SEG || (i == n - 1 && !segs.empty())) {
+            rc = run(segs[0].h, op, io, in_a, in_b, seed, offset, N, T, out_x, out_pdf, stream, &segs);
+            segs.clear();
+        }
+    }
+    return rc;
 }
 
 }  // namespace
@@ -1093,6 +1177,25 @@ int bsdfd_plugin_pdf(bsdfd_handle h, int32_t variant, const float* wi, const flo
         return fail(BSDFD_EINVAL, "unknown plugin variant");
     return run(h, OP_PDF, variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, wo, 0, 0, N, T,
                nullptr, pdf_sa, stream);
+}
+
+int bsdfd_plugin_sample_multi(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end, int32_t variant,
+                              const float* wi, const float* x0, uint64_t seed, uint64_t offset, int32_t T, float* wo,
+                              float* pdf_sa, void* stream) {
+    if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
+        return fail(BSDFD_EINVAL, "unknown plugin variant");
+    return run_multi(handles, n_handles, seg_end, OP_SAMPLE,
+                     variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, x0, seed, offset, T, wo,
+                     pdf_sa, stream);
+}
+
+int bsdfd_plugin_pdf_multi(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end, int32_t variant,
+                           const float* wi, const float* wo, int32_t T, float* pdf_sa, void* stream) {
+    if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
+        return fail(BSDFD_EINVAL, "unknown plugin variant");
+    return run_multi(handles, n_handles, seg_end, OP_PDF,
+                     variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, wo, 0, 0, T, nullptr,
+                     pdf_sa, stream);
 }
 
 int bsdfd_flow_samples_only(bsdfd_handle h, const float* omega_i, const float* x0, int64_t N, int32_t T,

@@ -4,16 +4,22 @@ The reference binds one plugin instance per material and Mitsuba dispatches each
 lane to its instance (one `sample()` call per material per bounce,
 rendering/matpreview/disney_bsdf_array0_envmap.xml: 12 `mybsdf` instances).  Here a
 ``MaterialTable`` holds one packed device handle per material and serves a batch whose
-queries carry a material id: queries are bucketed (stable sort by id), each non-empty
-bucket is ONE fused kernel launch on its contiguous slice, and results are scattered back
-to the callers' order.  All disk nets together are ~160 KB of fp16 fragments — the whole
-LDS — so keeping every material resident in one launch is not an option (SURVEY.md §7
-"mixed-material batches"); per-bucket launches keep each workgroup's LDS image to one
-material (16 KB) and lose nothing once buckets are >> 64 K queries.
+queries carry a material id: queries are bucketed (stable sort by id) and results are
+scattered back to the callers' order.  All disk nets together are ~160 KB of fp16 fragments
+— the whole LDS — so keeping every material resident in every workgroup is not an option
+(SURVEY.md §7 "mixed-material batches").  Instead ONE segmented launch
+(``bsdfd_plugin_sample_multi``) serves all buckets whose handles share a kernel signature
+(domain, width, depth, precision; up to 64 per launch): workgroups are dealt to the buckets
+in proportion to their sizes and each loads only its own material's 16 KB image.  The 52
+measured materials are 2 launches (27 disk + 25 spherical) instead of 52.
+``segmented=False`` falls back to one launch per bucket (used by the tests as the
+reference for the segmented path).
 """
 from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
+
+import ctypes as C
 
 import torch
 
@@ -56,6 +62,58 @@ class MaterialTable:
     def __len__(self):
         return len(self.samplers)
 
+    def _groups(self):
+        """Indices of materials grouped by kernel signature + plugin defaults (T, variant)."""
+        groups = {}
+        for m, s in enumerate(self.samplers):
+            fw = s.weights
+            key = (fw.domain, fw.width, fw.n_hidden, s.precision, self.T[m], self.variant[m])
+            groups.setdefault(key, []).append(m)
+        return groups
+
+    def _multi(self, which, members, seg_end_all, T, variant, wi_s, aux_s, seed, offset, out_wo, out_pdf):
+        """Segmented launch(es) for the materials `members` of one kernel signature.  The bucketed arrays
+        are ordered by material id, so a group's buckets may be interleaved with other groups'; each
+        maximal run of ADJACENT buckets becomes one `bsdfd_plugin_*_multi` call on the run's row range
+        (pointers advanced to the run's first row, Philox offset advanced by the same amount)."""
+        L = _lib.lib()
+        rc = 0
+        stream = C.c_void_p(torch.cuda.current_stream(wi_s.device).cuda_stream)
+        # the C ABI takes cumulative ends; non-adjacent buckets are issued as separate runs
+        run_h, run_end, base = [], [], None
+        def flush():
+            nonlocal run_h, run_end, base
+            if not run_h:
+                return 0
+            k = len(run_h)
+            arr_h = (C.c_void_p * k)(*run_h)
+            arr_e = (C.c_int64 * k)(*[e - base for e in run_end])
+            off_rows = base
+            wi_p = C.c_void_p(wi_s.data_ptr() + off_rows * 12)
+            if which == "sample":
+                x0_p = None if aux_s is None else C.c_void_p(aux_s.data_ptr() + off_rows * 8)
+                r = L.bsdfd_plugin_sample_multi(arr_h, k, arr_e, variant, wi_p, x0_p, seed, offset + off_rows, T,
+                                                C.c_void_p(out_wo.data_ptr() + off_rows * 12),
+                                                C.c_void_p(out_pdf.data_ptr() + off_rows * 4), stream)
+            else:
+                r = L.bsdfd_plugin_pdf_multi(arr_h, k, arr_e, variant, wi_p,
+                                             C.c_void_p(aux_s.data_ptr() + off_rows * 12), T,
+                                             C.c_void_p(out_pdf.data_ptr() + off_rows * 4), stream)
+            run_h, run_end, base = [], [], None
+            return r
+        prev_end = None
+        for m in members:
+            b, e = seg_end_all[m - 1] if m else 0, seg_end_all[m]
+            if prev_end is not None and b != prev_end:
+                rc = rc or flush()
+            if base is None:
+                base = b
+            run_h.append(self.samplers[m]._h)
+            run_end.append(e)
+            prev_end = e
+        rc = rc or flush()
+        _lib.check(rc)
+
     def _buckets(self, material_id: torch.Tensor):
         if material_id.dtype != torch.int64:
             material_id = material_id.long()
@@ -63,43 +121,57 @@ class MaterialTable:
         return perm, counts.cpu().tolist()
 
     def sample(self, material_id: torch.Tensor, wi: torch.Tensor, seed: int = 0, offset: int = 0,
-               T: Optional[int] = None, x0: Optional[torch.Tensor] = None):
+               T: Optional[int] = None, x0: Optional[torch.Tensor] = None, segmented: bool = True):
         """wi [N,3], material_id [N] -> (wo [N,3], pdf_sa [N]) in the callers' order.
-        The Philox counter of a query is ``offset + its position in the caller's batch``... after
-        bucketing positions change, so the stream is keyed per bucket: counter = offset + rank of
-        the query inside its bucket, seed mixed with the material index."""
+        The Philox counter of a query is ``offset + its row in the bucketed (sorted-by-material)
+        array``, identical for the segmented and the per-bucket path."""
         perm, counts = self._buckets(material_id)
         wi_s = wi[perm].contiguous()
         x0_s = None if x0 is None else x0[perm].contiguous()
         wo_s = torch.empty_like(wi_s)
         pdf_s = torch.empty(wi_s.shape[0], dtype=torch.float32, device=wi.device)
-        lo = 0
-        for m, n in enumerate(counts):
-            if n == 0:
-                continue
-            sl = slice(lo, lo + n)
-            self.samplers[m].plugin_sample(wi_s[sl], None if x0_s is None else x0_s[sl],
-                                           T=self.T[m] if T is None else T, variant=self.variant[m],
-                                           seed=seed * 1000003 + m, offset=offset, out=(wo_s[sl], pdf_s[sl]))
-            lo += n
+        if segmented:
+            seg_end = list(__import__("itertools").accumulate(counts))
+            with torch.cuda.device(wi.device):
+                for (dom, w, nh, prec, Tm, var), members in self._groups().items():
+                    self._multi("sample", members, seg_end, Tm if T is None else T, var, wi_s, x0_s, seed, offset,
+                                wo_s, pdf_s)
+        else:
+            lo = 0
+            for m, n in enumerate(counts):
+                if n == 0:
+                    continue
+                sl = slice(lo, lo + n)
+                # same Philox keying as the segmented path: counter = offset + row in the bucketed array
+                self.samplers[m].plugin_sample(wi_s[sl], None if x0_s is None else x0_s[sl],
+                                               T=self.T[m] if T is None else T, variant=self.variant[m],
+                                               seed=seed, offset=offset + lo, out=(wo_s[sl], pdf_s[sl]))
+                lo += n
         wo = torch.empty_like(wo_s)
         pdf = torch.empty_like(pdf_s)
         wo[perm] = wo_s
         pdf[perm] = pdf_s
         return wo, pdf
 
-    def pdf(self, material_id: torch.Tensor, wi: torch.Tensor, wo: torch.Tensor, T: Optional[int] = None):
+    def pdf(self, material_id: torch.Tensor, wi: torch.Tensor, wo: torch.Tensor, T: Optional[int] = None,
+            segmented: bool = True):
         perm, counts = self._buckets(material_id)
         wi_s, wo_s = wi[perm].contiguous(), wo[perm].contiguous()
         pdf_s = torch.empty(wi_s.shape[0], dtype=torch.float32, device=wi.device)
-        lo = 0
-        for m, n in enumerate(counts):
-            if n == 0:
-                continue
-            sl = slice(lo, lo + n)
-            self.samplers[m].plugin_pdf(wi_s[sl], wo_s[sl], T=self.T[m] if T is None else T,
-                                        variant=self.variant[m], out=pdf_s[sl])
-            lo += n
+        if segmented:
+            seg_end = list(__import__("itertools").accumulate(counts))
+            with torch.cuda.device(wi.device):
+                for (dom, w, nh, prec, Tm, var), members in self._groups().items():
+                    self._multi("pdf", members, seg_end, Tm if T is None else T, var, wi_s, wo_s, 0, 0, None, pdf_s)
+        else:
+            lo = 0
+            for m, n in enumerate(counts):
+                if n == 0:
+                    continue
+                sl = slice(lo, lo + n)
+                self.samplers[m].plugin_pdf(wi_s[sl], wo_s[sl], T=self.T[m] if T is None else T,
+                                            variant=self.variant[m], out=pdf_s[sl])
+                lo += n
         pdf = torch.empty_like(pdf_s)
         pdf[perm] = pdf_s
         return pdf

@@ -119,6 +119,20 @@ int bsdfd_plugin_sample(bsdfd_handle h, int32_t variant, const float* wi, const 
 int bsdfd_plugin_pdf(bsdfd_handle h, int32_t variant, const float* wi, const float* wo, int64_t N,
                      int32_t T, float* pdf_sa, void* hip_stream);
 
+/* Mixed-material batches (BASELINE.json configs[3]; the reference binds one plugin instance per material,
+ * rendering/matpreview/disney_bsdf_array0_envmap.xml, and Mitsuba calls each instance on its lanes).
+ * The query arrays are BUCKETED by material: bucket i = rows [seg_end[i-1], seg_end[i]) (seg_end is a HOST
+ * array of n_handles cumulative ends; empty buckets allowed) is served by handles[i].  All handles must
+ * share domain, width, depth, precision and device; ONE launch serves up to 64 buckets (workgroups are
+ * dealt to buckets in proportion to their sizes, each loads its material's weight image into LDS).
+ * The Philox counter of a row is offset + its row index in the bucketed array. */
+int bsdfd_plugin_sample_multi(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end,
+                              int32_t variant, const float* wi, const float* x0, uint64_t seed,
+                              uint64_t offset, int32_t T, float* wo, float* pdf_sa, void* hip_stream);
+int bsdfd_plugin_pdf_multi(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end,
+                           int32_t variant, const float* wi, const float* wo, int32_t T, float* pdf_sa,
+                           void* hip_stream);
+
 /* Reflow teacher sampling without the Jacobian: x <- x + v(x, t/T | omega_i)/T for T steps
  * (learning_repo_cleanup/spherical_domain_sampling.py:147-166, disk_domain_sampling.py:93-110 —
  * the reference's only tiny-cuda-nn call site). x0 [N,2] in, x_out [N,2] out. */

@@ -96,17 +96,47 @@ def test_mixed_material_table_matches_per_material_calls():
     ids[:100] = 3  # make sure ordering inside a bucket is exercised
     g, _ = load_case("chm_orange_rgb_disk")
     x0 = torch.from_numpy(np.tile(g["x0"], (n // 2048 + 1, 1))[:n]).to(_dev())
-    wo, pdf = tab.sample(ids, wi, x0=x0)
+    wo, pdf = tab.sample(ids, wi, x0=x0)                       # ONE segmented launch for the 4 disk materials
     p = tab.pdf(ids, wi, wo)
     for m in range(len(stems)):
         sel = (ids == m).nonzero()[:, 0]
         wo_m, pdf_m = tab.samplers[m].plugin_sample(wi[sel].contiguous(), x0[sel].contiguous(), T=4)
         assert torch.equal(wo[sel], wo_m) and torch.equal(pdf[sel], pdf_m)
         assert torch.equal(p[sel], tab.samplers[m].plugin_pdf(wi[sel].contiguous(), wo[sel].contiguous(), T=4))
-    # an id with no queries is fine
+    # segmented == one launch per bucket, bit for bit, also with the in-kernel RNG (counter = bucketed row)
+    a = tab.sample(ids, wi, seed=11, offset=5)
+    b = tab.sample(ids, wi, seed=11, offset=5, segmented=False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(tab.pdf(ids, wi, a[0]), tab.pdf(ids, wi, a[0], segmented=False))
+    # an id with no queries is fine; so is a single-row bucket
     ids2 = torch.zeros(1000, dtype=torch.int64, device=_dev())
-    wo2, _ = tab.sample(ids2, wi[:1000].contiguous(), seed=3)
-    assert torch.isfinite(wo2).all()
+    ids2[7] = 2
+    wo2, pdf2 = tab.sample(ids2, wi[:1000].contiguous(), seed=3)
+    wo3, pdf3 = tab.sample(ids2, wi[:1000].contiguous(), seed=3, segmented=False)
+    assert torch.isfinite(wo2).all() and torch.equal(wo2, wo3) and torch.equal(pdf2, pdf3)
+
+
+def test_mixed_domains_and_more_than_64_buckets():
+    """Disk + spherical + full-sphere materials interleaved by id (runs of adjacent buckets per kernel
+    signature), and a table of 77 materials (> 64 buckets: the ABI splits the launch)."""
+    from bsdf_diffusion_sampling_amd import weights as W
+    from bsdf_diffusion_sampling_amd.materials import MaterialTable
+    stems = ["chm_orange_rgb_disk", "chm_orange_rgb_spherical", "bsdf_3_spherical", "aniso_miro_7_rgb_disk",
+             "aniso_miro_7_rgb_spherical", "bsdf_7_spherical", "vch_silk_blue_rgb_disk"]
+    tab = MaterialTable(stems)
+    n = 30011
+    wi = _wi("spherical", n, 9)
+    ids = torch.randint(0, len(stems), (n,), generator=torch.Generator().manual_seed(4)).to(_dev())
+    a = tab.sample(ids, wi, seed=2)
+    b = tab.sample(ids, wi, seed=2, segmented=False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(tab.pdf(ids, wi, a[0]), tab.pdf(ids, wi, a[0], segmented=False))
+    big = MaterialTable(W.list_shipped("disk") + W.list_shipped("spherical"))
+    assert len(big) == 77
+    ids = torch.randint(0, 77, (n,), generator=torch.Generator().manual_seed(6)).to(_dev())
+    a = big.sample(ids, wi, seed=8)
+    b = big.sample(ids, wi, seed=8, segmented=False)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.isfinite(a[1]).all()
 
 
 def test_all_shipped_weight_sets_run_and_are_sane():

@@ -3,7 +3,7 @@
 
   mixed    BASELINE.json configs[3] per-GPU share: all 52 measured materials (27 disk T=4 + 25
            spherical T=8), 16 Mi queries with a uniformly random material id, bucketed by id,
-           one fused launch per bucket, sample() + pdf().
+           ONE segmented launch per kernel signature (27 disk + 25 spherical materials = 2 launches) for sample() and 2 for pdf().
   teacher  the reference's only tiny-cuda-nn call site (reflow `dosampling`,
            learning_repo_cleanup/spherical_domain_sampling.py:147-166): 64-wide x 6 teacher net,
            4 Mi rows, T = 128 Euler steps, no Jacobian, fp16.
@@ -55,7 +55,7 @@ def main():
             flops += 2 * c * tab.samplers[m].flops_per_query(tab.T[m])
         print(json.dumps({"workload": "mixed_52materials_16Mi", "Msamples_per_s": n / dt / 1e6, "ms_per_step": dt * 1e3,
                           "materials": len(tab), "algorithmic_TFLOPs": flops / dt / 1e12,
-                          "note": "includes the bucketing sort/gather/scatter (torch) around 104 fused launches"}))
+                          "note": "includes the bucketing sort/gather/scatter (torch) around 4 segmented launches (2 sample + 2 pdf)"}))
     else:
         n, T = 1 << 22, 128
         fw = W.load(W.shipped_path("aniso_miro_7_rgb", "spherical", "complex"))
