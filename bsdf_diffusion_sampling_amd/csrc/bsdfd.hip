@@ -57,6 +57,9 @@ constexpr int PE_SLABS = PE_BANDS + 1;  // K=4 slabs: one per band (sin/cos x 2 
 // hi*hi + hi*lo + lo*hi accumulate into ONE fp32 accumulator.
 
 enum { OP_SAMPLE = 0, OP_PDF = 1, OP_SAMPLES_ONLY = 2 };
+#ifndef BSDFD_TPREC
+#define BSDFD_TPREC 3
+#endif
 constexpr int MAX_SEG = 64;  // materials per segmented launch (the descriptors travel in the kernel arguments)
 enum { IO_OPERATOR = 0, IO_PLUGIN = 1, IO_PLUGIN_FULLSPHERE = 2 };
 
@@ -183,35 +186,45 @@ __device__ __forceinline__ float softplus(float x) {  // nn.Softplus(beta=1, thr
     return x > 20.0f ? x : log1pf(expf(x));
 }
 
-// Best & Fisher rejection sampler for VonMises(mu, kappa); the proposal constant is formed
-// in fp64 as torch does (torch/distributions/von_mises.py::_rejection_sample) because
-// tau - sqrt(2 tau) cancels catastrophically in fp32 for small kappa.
-__device__ float von_mises_sample(float mu, float kappa, unsigned k0, unsigned k1, unsigned q_lo,
-                                  unsigned q_hi) {
-    const double kd = (double)kappa;
-    double rr;
-    if (kd < 1e-5) {
-        rr = 1.0 / kd + kd;
+// Best & Fisher rejection sampler for VonMises(mu, kappa)
+// (torch/distributions/von_mises.py::_rejection_sample; call site rendering/utils/model.py:305).
+// * Proposal constant: torch forms rho = (tau - sqrt(2 tau)) / (2 kappa) in fp64 because the difference
+//   cancels in fp32; here the rationalised form rho = 2 kappa / (tau + sqrt(2 tau)) (tau (tau - 2) =
+//   4 kappa^2) has no cancellation and is evaluated in fp32.  r only shapes the envelope — the
+//   accept test uses the same r, so the sampler is exact for any r > 1.
+// * The 4 lanes of a query (lane = 16 g + q) test 4 CONSECUTIVE proposals of the query's Philox
+//   stream at once (proposal index 4 round + g); the first accepted one in stream order wins, so the
+//   draw equals the sequential loop's while a wave needs ~1.2 rounds instead of ~3.5 (max over its
+//   16 queries of a geometric trip count with acceptance >= 0.66).
+__device__ __forceinline__ float von_mises_sample(float mu, float kappa, unsigned k0, unsigned k1, unsigned q_lo,
+                                                  unsigned q_hi, int lane) {
+    float r;
+    if (kappa < 1e-5f) {
+        r = 1.0f / kappa + kappa;
     } else {
-        const double tau = 1.0 + sqrt(1.0 + 4.0 * kd * kd);
-        const double rho = (tau - sqrt(2.0 * tau)) / (2.0 * kd);
-        rr = (1.0 + rho * rho) / (2.0 * rho);
+        const float tau = 1.0f + sqrtf(1.0f + 4.0f * kappa * kappa);
+        const float rho = 2.0f * kappa / (tau + sqrtf(2.0f * tau));
+        r = (1.0f + rho * rho) / (2.0f * rho);
     }
-    const float r = (float)rr;
+    const int g = lane >> 4, q = lane & 15;
     float x = 0.0f;
-    for (unsigned it = 0; it < 256u; ++it) {
+    bool done = false;
+    for (unsigned round = 0; round < 64u; ++round) {
         unsigned u[4];
-        philox4x32(k0, k1, q_lo, q_hi, it + 1u, 0x564d6973u, u);  // "VMis"
+        philox4x32(k0, k1, q_lo, q_hi, round * 4u + (unsigned)g + 1u, 0x564d6973u, u);  // "VMis"
         const float u1 = u01_open(u[0]), u2 = u01_open(u[1]), u3 = u01_open(u[2]);
         const float z = cospif(u1);
         const float f = (1.0f + r * z) / (r + z);
         const float c = kappa * (r - f);
         const bool accept = (c * (2.0f - c) - u2 > 0.0f) || (logf(c / u2) + 1.0f - c >= 0.0f);
-        if (accept) {
-            const float a = acosf(fminf(fmaxf(f, -1.0f), 1.0f));
-            x = (u3 - 0.5f) < 0.0f ? -a : a;
-            break;
-        }
+        const float a = acosf(fminf(fmaxf(f, -1.0f), 1.0f));
+        const float cand = (u3 - 0.5f) < 0.0f ? -a : a;
+        const unsigned long long acc_mask = __builtin_amdgcn_ballot_w64(accept);
+        const unsigned long long mine = (acc_mask >> q) & 0x0001000100010001ull;  // bit 16 g' = lane (g', q)
+        const int first_g = mine ? (__builtin_ctzll(mine) >> 4) : 0;
+        const float got = __shfl(cand, first_g * 16 + q, 64);
+        if (!done && mine) { x = got; done = true; }
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
     }
     const float two_pi = 6.28318530717958647692f, pi = 3.14159265358979323846f;
     float w = fmodf(x + pi + mu, two_pi);
@@ -437,7 +450,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                 x1 = bo[1] + rad * sn * fexp0(bo[3]);
             } else {                            // model.py:298-307
                 x0 = bo[0] + rad * cs * (fexp0(bo[1]) + 1e-3f);
-                x1 = von_mises_sample(bo[2], kappa, k0, k1, (unsigned)ctr, (unsigned)(ctr >> 32));
+                x1 = von_mises_sample(bo[2], kappa, k0, k1, (unsigned)ctr, (unsigned)(ctr >> 32), lane);
             }
         }
 
@@ -560,7 +573,10 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                 // with the VALU work of the next measured no faster: on gfx950 a 16x16x32 MFMA hides
                 // only ~3 VALU issues, tools/ubench/mfma_overlap.hip — MFMA and VALU time add.)
                 constexpr bool SPLIT = (PREC == BSDFD_PREC_SPLIT3);
-#pragma unroll
+                constexpr bool TSPLIT = SPLIT && (BSDFD_TPREC == 3);   // tangents: hi+lo operands
+                constexpr bool TWLO = SPLIT && (BSDFD_TPREC >= 2);     // tangents: W_lo product
+                constexpr int LAYER_UNROLL = NH ? NH : 1;  // run-time depth: keep the loop rolled
+#pragma unroll LAYER_UNROLL
                 for (int layer = 0; layer < n_hidden; ++layer) {
                     const bool last = (layer == n_hidden - 1);
                     Frag bh[KC], bl[KC], b0h[KC], b0l[KC], b1h[KC], b1l[KC];
@@ -579,8 +595,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                         const int kc = m >> 1, q0 = 2 * (m & 1);
                         split_pack<SPLIT>(hv, bh[kc].p[q0], bh[kc].p[q0 + 1], bl[kc].p[q0], bl[kc].p[q0 + 1]);
                         if (JAC) {
-                            split_pack<SPLIT>(t0v, b0h[kc].p[q0], b0h[kc].p[q0 + 1], b0l[kc].p[q0], b0l[kc].p[q0 + 1]);
-                            split_pack<SPLIT>(t1v, b1h[kc].p[q0], b1h[kc].p[q0 + 1], b1l[kc].p[q0], b1l[kc].p[q0 + 1]);
+                            split_pack<TSPLIT>(t0v, b0h[kc].p[q0], b0h[kc].p[q0 + 1], b0l[kc].p[q0], b0l[kc].p[q0 + 1]);
+                            split_pack<TSPLIT>(t1v, b1h[kc].p[q0], b1h[kc].p[q0 + 1], b1l[kc].p[q0], b1l[kc].p[q0 + 1]);
                         }
                     }
                     if (!last) {
@@ -607,14 +623,14 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 #pragma unroll
                                 for (int mo = 0; mo < NM; ++mo) {
                                     a[mo] = mfma16(wh[mo], bl[kc].v, a[mo]);
-                                    if (JAC) { a0[mo] = mfma16(wh[mo], b0l[kc].v, a0[mo]); a1[mo] = mfma16(wh[mo], b1l[kc].v, a1[mo]); }
+                                    if (JAC && TSPLIT) { a0[mo] = mfma16(wh[mo], b0l[kc].v, a0[mo]); a1[mo] = mfma16(wh[mo], b1l[kc].v, a1[mo]); }
                                 }
 #endif
 #if !(BSDFD_ABL & 16)  // ablation: drop W_lo * x_hi  (p99 pdf error 1.8e-5 -> 2e-3 .. 7e-2)
 #pragma unroll
                                 for (int mo = 0; mo < NM; ++mo) {
                                     a[mo] = mfma16(wl[mo], bh[kc].v, a[mo]);
-                                    if (JAC) { a0[mo] = mfma16(wl[mo], b0h[kc].v, a0[mo]); a1[mo] = mfma16(wl[mo], b1h[kc].v, a1[mo]); }
+                                    if (JAC && TWLO) { a0[mo] = mfma16(wl[mo], b0h[kc].v, a0[mo]); a1[mo] = mfma16(wl[mo], b1h[kc].v, a1[mo]); }
                                 }
 #endif
                             }
@@ -632,7 +648,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                             if (JAC) { e0 = mfma16(wo, b0h[kc].v, e0); e1 = mfma16(wo, b1h[kc].v, e1); }
                             if (SPLIT) {
                                 e = mfma16(wo, bl[kc].v, e);
-                                if (JAC) { e0 = mfma16(wo, b0l[kc].v, e0); e1 = mfma16(wo, b1l[kc].v, e1); }
+                                if (JAC && TSPLIT) { e0 = mfma16(wo, b0l[kc].v, e0); e1 = mfma16(wo, b1l[kc].v, e1); }
                             }
                         }
                         v[0] = e[0] + e[2]; v[1] = e[1] + e[3];

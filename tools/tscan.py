@@ -12,6 +12,8 @@ for stem in stems:
     wi=t(np.tile(g["wi"],(N//2048,1))); x0=t(np.tile(g["x0"],(N//2048,1)))
     for prec in ("split3","f16"):
         s=FlowSampler(fw,precision=prec); s.set_profiling(True)
+        t0=time.time()
+        while time.time()-t0<0.15: s.network_sampling(wi,x0,T=8); torch.cuda.synchronize()  # leave the idle clocks (tools/ramp.py)
         res={}
         for T in (1,2,4,8,16,32):
             for _ in range(2): s.network_sampling(wi,x0,T=T)
