@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("BSDFD_LIB_PATH") or os.path.join(_HERE, "libbsdfd.so")  # override: A/B builds
 SRC_PATH = os.path.join(_HERE, "csrc", "bsdfd.hip")
+SRC_PATHS = [SRC_PATH, os.path.join(_HERE, "csrc", "wavefront.hip")]  # translation units of libbsdfd.so
+DEP_PATHS = SRC_PATHS + [os.path.join(_HERE, "csrc", "common.h")]
 INCLUDE_DIR = os.path.join(ROOT, "include")
 
 PREC_DEFAULT, PREC_F32, PREC_SPLIT3, PREC_F16 = 0, 1, 2, 3
@@ -24,9 +26,17 @@ EXPORTS = (
     "bsdfd_create", "bsdfd_create_from_file", "bsdfd_destroy", "bsdfd_get_info",
     "bsdfd_flops_per_query", "bsdfd_network_sampling", "bsdfd_network_pdf",
     "bsdfd_plugin_sample", "bsdfd_plugin_pdf", "bsdfd_plugin_sample_multi", "bsdfd_plugin_pdf_multi",
-    "bsdfd_flow_samples_only",
+    "bsdfd_flow_samples_only", "bsdfd_wf_primary", "bsdfd_wf_shade",
     "bsdfd_set_profiling", "bsdfd_profile_read", "bsdfd_last_kernel_ms", "bsdfd_last_error", "bsdfd_version",
 )
+
+
+class WfScene(C.Structure):
+    """bsdfd_wf_scene (include/bsdfd.h)."""
+    _fields_ = [("cam_origin", C.c_float * 3), ("cam_right", C.c_float * 3), ("cam_up", C.c_float * 3),
+                ("cam_forward", C.c_float * 3), ("tan_half_fov", C.c_float), ("width", C.c_int32),
+                ("height", C.c_int32), ("sphere_center", C.c_float * 3), ("sphere_radius", C.c_float),
+                ("albedo", C.c_float * 3), ("env_width", C.c_int32), ("env_height", C.c_int32)]
 
 
 class Desc(C.Structure):
@@ -40,10 +50,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile libbsdfd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     hdr = os.path.join(INCLUDE_DIR, "bsdfd.h")
     if (not force and os.path.exists(LIB_PATH)
-            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(SRC_PATH), os.path.getmtime(hdr))):
+            and os.path.getmtime(LIB_PATH) >= max([os.path.getmtime(hdr)] + [os.path.getmtime(f) for f in DEP_PATHS])):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           "-I", INCLUDE_DIR, SRC_PATH, "-o", LIB_PATH]
+           "-I", INCLUDE_DIR, *SRC_PATHS, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
@@ -81,6 +91,8 @@ def lib():
     L.bsdfd_plugin_sample_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, u64, u64, i32, fp, fp, vp]
     L.bsdfd_plugin_pdf_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, i32, fp, vp]
     L.bsdfd_flow_samples_only.argtypes = [vp, fp, fp, i64, i32, fp, vp]
+    L.bsdfd_wf_primary.argtypes = [C.POINTER(WfScene), i32, i32, i32, u64, u64, fp, fp, fp, fp, vp]
+    L.bsdfd_wf_shade.argtypes = [C.POINTER(WfScene), fp, i32, i32, i32, fp, fp, fp, fp, fp, fp, fp, vp]
     L.bsdfd_set_profiling.argtypes = [vp, i32]
     L.bsdfd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]
     L.bsdfd_last_kernel_ms.argtypes = [vp]

@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "bsdfd.h"
+#include "common.h"
 
 #ifndef BSDFD_ABL
 #define BSDFD_ABL 0  // ablation bitmask for timing experiments under tools/ (always 0 in the product)
@@ -144,23 +145,6 @@ __device__ __forceinline__ void split_pack(const float (&x)[4], f16x2& h01, f16x
 
 __device__ __forceinline__ float sel4(int g, float a0, float a1, float a2, float a3) {
     return g == 0 ? a0 : (g == 1 ? a1 : (g == 2 ? a2 : a3));
-}
-
-// Philox4x32-10 counter-based RNG (Salmon et al., SC'11); stream = (seed; query index, draw index).
-__device__ __forceinline__ void philox4x32(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2,
-                                           unsigned c3, unsigned out[4]) {
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
-        const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-__device__ __forceinline__ float u01_open(unsigned x) {  // (0, 1]
-    return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
 }
 
 // log I0(kappa): the two polynomials of torch.distributions.von_mises._log_modified_bessel_fn
@@ -729,18 +713,14 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 // ---------------------------------------------------------------------------------------------
 thread_local std::string g_err;
 
-int fail(int code, const std::string& msg) {
+inline int fail(int code, const std::string& msg) { return bsdfd_fail_(code, msg); }
+
+}  // namespace
+
+int bsdfd_fail_(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
-#define HIP_TRY(expr)                                                                        \
-    do {                                                                                     \
-        hipError_t e__ = (expr);                                                             \
-        if (e__ != hipSuccess)                                                               \
-            return fail(BSDFD_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__));     \
-    } while (0)
-
-}  // namespace
 
 struct bsdfd_ctx {
     int domain, width, n_hidden, precision, state_dim, in_dim;

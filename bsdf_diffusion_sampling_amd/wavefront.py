@@ -1,0 +1,185 @@
+"""Wavefront harness (BASELINE.json config 5: "matpreview render, 1024 spp").
+
+The reference renders by handing its ``MyBSDF`` plugin to Mitsuba 3 and looping
+``mi.render(scene, spp=4, seed)`` 128-256 times (rendering/brdf_measured_disk.py:146-155);
+every pass the integrator calls the plugin's ``sample()`` once per path (and ``pdf()`` once
+per emitter sample).  Mitsuba is not available to this build, so the harness supplies the
+minimum around the SAME plugin entry points — primary rays as in
+rendering/utils/mitsuba_helper.py:59-127, the power heuristic of :130-137, one analytic
+sphere carrying the material, a lat-long environment map, one bounce — which is enough to
+drive the hot path exactly the way a renderer does: one ``sample_t`` and one ``pdf_t`` call
+per wavefront of (tile pixels x spp) paths per pass, image rows split across GPUs.
+
+Per pass and tile (both streaming kernels live in csrc/wavefront.hip, C ABI ``bsdfd_wf_*``):
+
+    primary  -> wi, wl (cosine light sample), normal, ray dir      48 B/path written
+    plugin.sample_t(wi)        -> wo, pdf(wo)                      the hot path (fused flow kernel)
+    plugin.pdf_t(wi, wl)       -> pdf(wl)                          the hot path
+    shade    -> film tile += mean_spp of the MIS estimate          80 B/path read
+
+The ground-truth ``eval()`` of the reference is Mitsuba's ``measured`` BSDF (not neural, not
+part of this build).  The nets model pdf(wo | wi) ∝ lum(f cos), so the harness shades with
+the proxy ``f cos = albedo * pdf`` — BSDF samples carry weight ``albedo``, light samples
+``albedo * pdf_bsdf / pdf_light`` — a consistent one-bounce estimator whose cost profile
+(one sample() + one pdf() per path) is that of the reference's render.
+
+There is no CPU fallback: every step goes through libbsdfd.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import math
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .sharding import shard_range
+
+
+@dataclasses.dataclass
+class Camera:
+    """Pinhole camera; ``fov_deg`` is the horizontal field of view (Mitsuba's default fov_axis = x)."""
+    origin: Sequence[float] = (0.0, 0.6, 3.2)
+    target: Sequence[float] = (0.0, 0.0, 0.0)
+    up: Sequence[float] = (0.0, 1.0, 0.0)
+    fov_deg: float = 40.0
+    width: int = 512
+    height: int = 512
+
+    def basis(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        o, t, u = (np.asarray(v, dtype=np.float64) for v in (self.origin, self.target, self.up))
+        f = t - o
+        f /= np.linalg.norm(f)
+        r = np.cross(f, u)
+        r /= np.linalg.norm(r)
+        return r, np.cross(r, f), f
+
+
+def make_sky(height: int = 256, width: int = 512, seed: int = 0) -> torch.Tensor:
+    """Synthetic lat-long environment [H,W,3] (y up): horizon gradient + a sun + a few soft lights.
+    (The reference's matpreview/envmap.exr needs an OpenEXR reader and is not redistributable data.)"""
+    g = np.random.default_rng(seed)
+    v = (np.arange(height) + 0.5) / height
+    u = (np.arange(width) + 0.5) / width
+    theta, phi = np.pi * v[:, None], 2 * np.pi * u[None, :]
+    d = np.stack([np.sin(theta) * np.sin(phi), np.cos(theta) * np.ones_like(phi), -np.sin(theta) * np.cos(phi)], -1)
+    up = np.clip(d[..., 1], 0, 1)[..., None]
+    env = 0.25 * (1 - up) * np.array([1.0, 0.95, 0.9]) + 0.6 * up * np.array([0.45, 0.6, 1.0])
+    env = np.where(d[..., 1:2] < 0, 0.08 * np.array([0.5, 0.45, 0.4]), env)
+    for _ in range(5):
+        c = g.normal(size=3)
+        c[1] = abs(c[1]) + 0.2
+        c /= np.linalg.norm(c)
+        sharp = g.uniform(20, 400)
+        col = g.uniform(0.5, 1.0, size=3) * g.uniform(2, 30)
+        env = env + np.exp(sharp * (d @ c - 1.0))[..., None] * col
+    return torch.from_numpy(env.astype(np.float32))
+
+
+class WavefrontRenderer:
+    """One material ball under an environment map, rendered in passes of ``spp`` samples per pixel.
+
+    ``plugin`` is any of the ``MyBSDF`` mirrors (``sample_t`` / ``pdf_t``; its ``albedo`` tints the result).
+    """
+
+    def __init__(self, plugin, camera: Optional[Camera] = None, env: Optional[torch.Tensor] = None,
+                 sphere_center: Sequence[float] = (0.0, 0.0, 0.0), sphere_radius: float = 1.0,
+                 device: Optional[torch.device] = None):
+        self.plugin = plugin
+        self.camera = camera or Camera()
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        env = make_sky() if env is None else env
+        if env.dim() != 3 or env.shape[2] != 3:
+            raise ValueError("env must be [H,W,3]")
+        self.env = env.to(self.device, torch.float32).contiguous()
+        r, u, f = self.camera.basis()
+        sc = _lib.WfScene()
+        for name, val in (("cam_origin", self.camera.origin), ("cam_right", r), ("cam_up", u), ("cam_forward", f),
+                          ("sphere_center", sphere_center),
+                          ("albedo", [float(a) for a in getattr(plugin, "albedo", torch.ones(3)).tolist()])):
+            setattr(sc, name, (C.c_float * 3)(*[float(x) for x in val]))
+        sc.tan_half_fov = math.tan(math.radians(self.camera.fov_deg) * 0.5)
+        sc.width, sc.height = int(self.camera.width), int(self.camera.height)
+        sc.sphere_radius = float(sphere_radius)
+        sc.env_height, sc.env_width = int(self.env.shape[0]), int(self.env.shape[1])
+        self.scene = sc
+        self._buf = {}
+
+    # -- buffers -----------------------------------------------------------------------------------
+    def _buffers(self, n: int):
+        b = self._buf.get(n)
+        if b is None:
+            mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.device)
+            b = dict(wi=mk(n, 3), wl=mk(n, 3), nrm=mk(n, 3), dir=mk(n, 3), wo=mk(n, 3), pdf_o=mk(n), pdf_l=mk(n))
+            self._buf = {n: b}  # one tile shape at a time
+        return b
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- the two harness kernels ---------------------------------------------------------------------
+    def primary(self, row_begin: int, row_end: int, spp: int, seed: int, pass_idx: int, out=None):
+        """-> dict(wi, wl, nrm, dir), each [N,3], N = (row_end-row_begin) * width * spp."""
+        n = (row_end - row_begin) * self.camera.width * spp
+        b = out or self._buffers(n)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().bsdfd_wf_primary(C.byref(self.scene), row_begin, row_end, spp, seed, pass_idx,
+                                                   p(b["wi"]), p(b["wl"]), p(b["nrm"]), p(b["dir"]), self._stream()))
+        return b
+
+    def shade(self, row_begin: int, row_end: int, spp: int, b, film: torch.Tensor):
+        """film [row_end-row_begin, width, 3] += the pass' estimate."""
+        if film.shape != (row_end - row_begin, self.camera.width, 3) or film.dtype != torch.float32 \
+                or not film.is_contiguous() or film.device != self.device:
+            raise ValueError("film must be a contiguous fp32 [rows, width, 3] tensor on the renderer's device")
+        p = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().bsdfd_wf_shade(C.byref(self.scene), p(self.env), row_begin, row_end, spp,
+                                                 p(b["wo"]), p(b["pdf_o"]), p(b["wl"]), p(b["pdf_l"]), p(b["nrm"]),
+                                                 p(b["dir"]), p(film), self._stream()))
+
+    # -- one pass over a tile ------------------------------------------------------------------------
+    def render_pass(self, film: torch.Tensor, row_begin: int, row_end: int, spp: int, seed: int, pass_idx: int,
+                    x0: Optional[torch.Tensor] = None):
+        n = (row_end - row_begin) * self.camera.width * spp
+        if n == 0:
+            return
+        b = self.primary(row_begin, row_end, spp, seed, pass_idx)
+        core = self.plugin
+        # sample(): Philox counter = global path index, key = (seed, pass) -> independent of the row split
+        offset = row_begin * self.camera.width * spp
+        skey = (seed * 0x9E3779B97F4A7C15 + pass_idx + 1) & 0xFFFFFFFFFFFFFFFF
+        core.sampler.plugin_sample(b["wi"], x0, T=core.T, variant=core.VARIANT, seed=skey, offset=offset,
+                                   out=(b["wo"], b["pdf_o"]))
+        core.sampler.plugin_pdf(b["wi"], b["wl"], T=core.T, variant=core.VARIANT, out=b["pdf_l"])
+        self.shade(row_begin, row_end, spp, b, film)
+
+    def render(self, passes: int, spp: int = 4, seed: int = 0, rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:
+        """Mean of ``passes`` passes of ``spp`` samples per pixel over rows [rows[0], rows[1]) (default:
+        the whole film) -> [rows, width, 3].  The reference's loop: brdf_measured_disk.py:146-155
+        (its `seed` is not advanced on the first iteration — fixed here: pass index = RNG stream)."""
+        r0, r1 = rows if rows is not None else (0, self.camera.height)
+        film = torch.zeros((r1 - r0, self.camera.width, 3), dtype=torch.float32, device=self.device)
+        for k in range(passes):
+            self.render_pass(film, r0, r1, spp, seed, k)
+        return film / max(passes, 1)
+
+    def render_sharded(self, passes: int, spp: int = 4, seed: int = 0, gather: bool = True):
+        """Image-tile split (config 5): rank r renders a contiguous block of rows; the only exchange is
+        the final gather of the film tiles (<= 3 MiB for 512^2) to rank 0.  Returns the full image on
+        rank 0 (None elsewhere), or the local tile when ``gather`` is False."""
+        import torch.distributed as dist
+        from .sharding import gather_to_root
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        r0, r1 = shard_range(self.camera.height, rank, world)
+        tile = self.render(passes, spp, seed, rows=(r0, r1))
+        if world == 1 or not gather:
+            return tile
+        w = self.camera.width
+        full = gather_to_root(tile.reshape(r1 - r0, w * 3), self.camera.height)
+        return None if full is None else full.reshape(self.camera.height, w, 3)

@@ -150,6 +150,37 @@ int bsdfd_set_profiling(bsdfd_handle h, int32_t enable);
 int bsdfd_profile_read(bsdfd_handle h, int64_t* n_launches, double* total_ms);
 float bsdfd_last_kernel_ms(bsdfd_handle h);
 
+/* ---- wavefront harness ------------------------------------
+ * The reference renders through Mitsuba 3 (rendering/brdf_measured_disk.py:146-155: passes of
+ * `mi.render(scene, spp=4, seed)`), whose integrator calls the plugin's sample()/pdf() once per
+ * wavefront; rendering/utils/mitsuba_helper.py:59-127 restates the primary-ray generation and
+ * :130-137 the power-heuristic MIS weight.  These two streaming kernels are the part of that loop
+ * around the plugin calls for a minimal scene of the harness' own: pinhole camera, one analytic
+ * sphere carrying the material, a lat-long environment map (y up), one bounce.  Path index inside a
+ * tile of rows [row_begin, row_end): ((row - row_begin) * width + col) * spp + s; the RNG counter is
+ * the global path index, so an image does not depend on the row split over GPUs. */
+typedef struct bsdfd_wf_scene {
+    float cam_origin[3], cam_right[3], cam_up[3], cam_forward[3]; /* orthonormal camera basis */
+    float tan_half_fov;                                            /* of the horizontal field of view */
+    int32_t width, height;                                         /* film size in pixels */
+    float sphere_center[3];
+    float sphere_radius;
+    float albedo[3];                                               /* props["albedo"] of the plugin */
+    int32_t env_width, env_height;                                 /* environment map [H,W,3] fp32 */
+} bsdfd_wf_scene;
+
+/* Primary rays of rows [row_begin,row_end), spp jittered samples per pixel, pass index `pass`:
+ * wi [N,3] local incoming direction ((0,0,1) for rays that miss the sphere), wl [N,3] cosine-weighted
+ * light-sample direction (local), nrm [N,3] world normal (0 for a miss), dir [N,3] world ray direction. */
+int bsdfd_wf_primary(const bsdfd_wf_scene* scene, int32_t row_begin, int32_t row_end, int32_t spp,
+                     uint64_t seed, uint64_t pass, float* wi, float* wl, float* nrm, float* dir,
+                     void* hip_stream);
+/* One-bounce MIS estimate: wo/pdf_o from plugin sample(), pdf_l = plugin pdf(wi, wl);
+ * film [row_end-row_begin, width, 3] += mean over the spp samples of a pixel. */
+int bsdfd_wf_shade(const bsdfd_wf_scene* scene, const float* env, int32_t row_begin, int32_t row_end,
+                   int32_t spp, const float* wo, const float* pdf_o, const float* wl, const float* pdf_l,
+                   const float* nrm, const float* dir, float* film, void* hip_stream);
+
 const char* bsdfd_last_error(void);
 const char* bsdfd_version(void);
 
