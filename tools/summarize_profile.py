@@ -38,6 +38,18 @@ def main():
         if "flow_kernel" in r["Name"]:
             out["kernel_trace"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]),
                                    "max_ns": float(r["MaxNs"]), "percentage": float(r["Percentage"])}
+    # the stats average covers EVERY launch of the command (clock-settle phase, warm-up, timed region, per-kind
+    # split); the per-launch trace lets us average exactly the timed region's launches as bench.py's events do
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 50
+    tr = glob.glob(os.path.join(src, "trace", "trace_kernel_trace.csv"))
+    if tr and "kernel_trace" in out:
+        rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr[0]))
+                if "flow_kernel" in r["Kernel_Name"]]
+        rows.sort()
+        timed = rows[-(2 * steps + 10):-10]  # bench.py: ..., 2*steps timed launches, then 5 sample + 5 pdf
+        if timed:
+            out["kernel_trace"]["timed_region_launches"] = len(timed)
+            out["kernel_trace"]["timed_region_avg_ns"] = sum(e - b for b, e in timed) / len(timed)
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         # rocprofv3 reports KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B: double it
         # (MI355X_MICROARCH.md §HBM; calibrated on this kernel's known 12/24 B-per-query reads)
