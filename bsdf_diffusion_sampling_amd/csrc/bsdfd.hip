@@ -84,11 +84,13 @@ struct KParams {
     // multi-material ("segmented") launch: the query arrays hold nseg contiguous buckets, one per
     // material; workgroups [blk_begin, blk_end) of the grid serve bucket [q_begin, q_end) with that
     // material's weight image.  nseg == 0: ordinary single-material launch over [0, N).
+    int chunk_log2;  // a wave takes 2^chunk_log2 consecutive-ish tiles per chunk (see the tile map in the kernel)
     int nseg;
     struct Seg {
         const char* img;
         long long q_begin, q_end;
         int blk_begin, blk_end;
+        int chunk_log2, pad;
     } seg[MAX_SEG];
 };
 
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
     // this workgroup's share of the work: the whole batch, or one material's bucket
     const char* img = p.img;
     long long q_begin = 0, q_end = p.N;
-    int blk = blockIdx.x, nblk = gridDim.x;
+    int blk = blockIdx.x, nblk = gridDim.x, cl = p.chunk_log2;
     if (p.nseg > 0) {
         int sidx = 0;
         for (int i = 1; i < p.nseg; ++i)
@@ -240,6 +242,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
         q_end = p.seg[sidx].q_end;
         blk = blockIdx.x - p.seg[sidx].blk_begin;
         nblk = p.seg[sidx].blk_end - p.seg[sidx].blk_begin;
+        cl = p.seg[sidx].chunk_log2;
     }
     {
         const uint4* src = reinterpret_cast<const uint4*>(img);
@@ -286,15 +289,17 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
     const float cstep = reverse ? -invT : invT;
     const long long ntiles = (q_end - q_begin + 15) / 16;
 
-    // Tile -> wave map: a workgroup takes CHUNKS of 8 x waves_per_block consecutive tiles, chunks
+    // Tile -> wave map: a workgroup takes CHUNKS of 2^cl x waves_per_block consecutive tiles, chunks
     // round-robin over the grid.  Consecutive tiles of a chunk stay on one CU (one XCD's L2), so the
     // 128-B lines of the query arrays are not fetched by two XCDs (a plain round-robin of single
     // tiles measured +35 % HBM reads), while the round-robin of chunks keeps the dynamic balance.
-    const long long chunk = 8LL * waves_per_block;
+    // cl = 3 for large batches; the host lowers it for small ones so that every CU gets work
+    // (64 Ki queries: 8-tile chunks would occupy 128 workgroups, 1-tile chunks 1024).
+    const long long chunk = (long long)waves_per_block << cl;
     for (long long it = 0;; ++it) {
-        const long long chunk_base = ((it >> 3) * nblk + blk) * chunk;
+        const long long chunk_base = ((it >> cl) * nblk + blk) * chunk;
         if (chunk_base >= ntiles) break;
-        const long long tile = chunk_base + (it & 7) * waves_per_block + wave;
+        const long long tile = chunk_base + (it & ((1 << cl) - 1)) * waves_per_block + wave;
         if (tile >= ntiles) continue;
         const long long qi_raw = q_begin + tile * 16 + q;
         const bool valid = qi_raw < q_end;
@@ -920,6 +925,7 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     kp.in_a = in_a; kp.in_b = in_b; kp.out_x = out_x; kp.out_pdf = out_pdf;
     kp.N = N; kp.T = T; kp.n_hidden = h->n_hidden; kp.op = op; kp.io = io; kp.seed = seed; kp.offset = offset;
     kp.nseg = 0;
+    kp.chunk_log2 = 3;
 
     const int NM = h->width / 16;
     const int threads = threads_for(NM);
@@ -935,10 +941,20 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
         if (v > 0) per_cu = v;
     }
     const long long cap = (long long)h->num_cu * per_cu * 4;
+    // tiles per wave and chunk: 8 when that still leaves >= `min_chunks` workgroup-chunks, else fewer
+    int cl_override = -1;
+    if (const char* ov = std::getenv("BSDFD_CHUNK_LOG2")) cl_override = std::atoi(ov);  // tuning knob (tools/nscan.py)
+    auto pick_cl = [&](long long ntiles, long long min_chunks) {
+        if (cl_override >= 0 && cl_override <= 3) return cl_override;
+        int cl = 3;
+        while (cl > 0 && ntiles / ((long long)waves << cl) < min_chunks) --cl;
+        return cl;
+    };
     long long nblocks;
     if (!segs) {
         const long long ntiles = (N + 15) / 16;
-        const long long want = (ntiles + waves - 1) / waves;
+        kp.chunk_log2 = pick_cl(ntiles, 8LL * h->num_cu);
+        const long long want = (ntiles + ((long long)waves << kp.chunk_log2) - 1) / ((long long)waves << kp.chunk_log2);
         nblocks = want < cap ? want : cap;
     } else {
         // workgroups are dealt to the buckets in proportion to their sizes (at least one each)
@@ -962,6 +978,8 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
             sg.blk_begin = b;
             b += (int)nb;
             sg.blk_end = b;
+            sg.chunk_log2 = pick_cl(((*segs)[i].q_end - (*segs)[i].q_begin + 15) / 16, 8LL * nb);
+            sg.pad = 0;
         }
         nblocks = b;
     }
