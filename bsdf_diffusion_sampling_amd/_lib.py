@@ -52,7 +52,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if (not force and os.path.exists(LIB_PATH)
             and os.path.getmtime(LIB_PATH) >= max([os.path.getmtime(hdr)] + [os.path.getmtime(f) for f in DEP_PATHS])):
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed",
            "-I", INCLUDE_DIR, *SRC_PATHS, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -564,8 +564,9 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                 constexpr bool SPLIT = (PREC == BSDFD_PREC_SPLIT3);
                 constexpr bool TSPLIT = SPLIT && (BSDFD_TPREC == 3);   // tangents: hi+lo operands
                 constexpr bool TWLO = SPLIT && (BSDFD_TPREC >= 2);     // tangents: W_lo product
-                constexpr int LAYER_UNROLL = NH ? NH : 1;  // run-time depth: keep the loop rolled
-#pragma unroll LAYER_UNROLL
+                // NH > 0: fully unrolled.  NH == 0 (run-time depth) cannot be, and clang says so (-Wpass-failed,
+                // silenced in the build line); an explicit `unroll 1` there measured 13 % slower on the 64-wide net
+#pragma unroll
                 for (int layer = 0; layer < n_hidden; ++layer) {
                     const bool last = (layer == n_hidden - 1);
                     Frag bh[KC], bl[KC], b0h[KC], b0l[KC], b1h[KC], b1l[KC];
