@@ -150,6 +150,13 @@ int bsdfd_set_profiling(bsdfd_handle h, int32_t enable);
 int bsdfd_profile_read(bsdfd_handle h, int64_t* n_launches, double* total_ms);
 float bsdfd_last_kernel_ms(bsdfd_handle h);
 
+/* Stand-alone positional encoding = the reference's positional_encoding_1 (rendering/utils/model.py:9-57):
+ * x [N,dim] -> out [N, dim * (include_input + 2 * bands)] = cat([x], sin(f_0 x), cos(f_0 x), ...), f = 2^b
+ * (log_sampling) or linspace(1, 2^(bands-1), bands).  Fused (and free) inside the flow kernel; this
+ * un-fused pass is the drop-in for the reference function and the HBM-bound "encoding pass". */
+int bsdfd_positional_encoding(const float* x, int64_t N, int32_t dim, int32_t bands, int32_t include_input,
+                              int32_t log_sampling, float* out, void* hip_stream);
+
 /* ---- wavefront harness ------------------------------------
  * The reference renders through Mitsuba 3 (rendering/brdf_measured_disk.py:146-155: passes of
  * `mi.render(scene, spp=4, seed)`), whose integrator calls the plugin's sample()/pdf() once per
