@@ -937,14 +937,17 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     const bool jac = op != OP_SAMPLES_ONLY;
     int per_cu = h->per_cu[jac ? 1 : 0];
     if (per_cu < 1) per_cu = 1;
-    if (const char* ov = std::getenv("BSDFD_BLOCKS_PER_CU")) {  // tuning knob (tools/tscan.py)
-        const int v = std::atoi(ov);
-        if (v > 0) per_cu = v;
-    }
+    static const int per_cu_override = [] {  // tuning knobs (tools/tscan.py, tools/nscan.py), read once
+        const char* ov = std::getenv("BSDFD_BLOCKS_PER_CU");
+        return ov ? std::atoi(ov) : 0;
+    }();
+    static const int cl_override = [] {
+        const char* ov = std::getenv("BSDFD_CHUNK_LOG2");
+        return ov ? std::atoi(ov) : -1;
+    }();
+    if (per_cu_override > 0) per_cu = per_cu_override;
     const long long cap = (long long)h->num_cu * per_cu * 4;
     // tiles per wave and chunk: 8 when that still leaves >= `min_chunks` workgroup-chunks, else fewer
-    int cl_override = -1;
-    if (const char* ov = std::getenv("BSDFD_CHUNK_LOG2")) cl_override = std::atoi(ov);  // tuning knob (tools/nscan.py)
     auto pick_cl = [&](long long ntiles, long long min_chunks) {
         if (cl_override >= 0 && cl_override <= 3) return cl_override;
         int cl = 3;

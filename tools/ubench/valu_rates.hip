@@ -39,6 +39,10 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, long long* cyc)
         if (WHICH == 8) { REP8(asm volatile("v_mul_f32 %0, %0, %0\n v_add_f32 %1, %1, %1\n v_mul_f32 %2, %2, %2\n v_add_f32 %3, %3, %3\n v_mul_f32 %4, %4, %4\n v_add_f32 %5, %5, %5\n v_mul_f32 %6, %6, %6\n v_add_f32 %7, %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
         if (WHICH == 9) { REP8(asm volatile("v_pk_mul_f32 %0, %0, %0\n v_pk_add_f32 %1, %1, %1\n v_pk_mul_f32 %2, %2, %2\n v_pk_add_f32 %3, %3, %3\n v_pk_mul_f32 %0, %0, %0\n v_pk_add_f32 %1, %1, %1\n v_pk_mul_f32 %2, %2, %2\n v_pk_add_f32 %3, %3, %3" : "+v"(*(double*)&c0), "+v"(*((double*)&c0 + 1)), "+v"(*(double*)&c1), "+v"(*((double*)&c1 + 1)));) }
         if (WHICH == 10) { REP8(asm volatile("v_cvt_f32_f16 %0, %0\n v_cvt_f32_f16 %1, %1\n v_cvt_f32_f16 %2, %2\n v_cvt_f32_f16 %3, %3\n v_cvt_f32_f16 %4, %4\n v_cvt_f32_f16 %5, %5\n v_cvt_f32_f16 %6, %6\n v_cvt_f32_f16 %7, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+        if (WHICH == 12) { REP8(asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1\n v_cvt_pkrtz_f16_f32 %2, %2, %3\n v_cvt_pkrtz_f16_f32 %4, %4, %5\n v_cvt_pkrtz_f16_f32 %6, %6, %7\n v_cvt_pkrtz_f16_f32 %1, %1, %0\n v_cvt_pkrtz_f16_f32 %3, %3, %2\n v_cvt_pkrtz_f16_f32 %5, %5, %4\n v_cvt_pkrtz_f16_f32 %7, %7, %6" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+        if (WHICH == 13) { REP8(asm volatile("v_and_b32 %0, %0, %1\n v_and_b32 %2, %2, %3\n v_and_b32 %4, %4, %5\n v_and_b32 %6, %6, %7\n v_and_b32 %1, %1, %0\n v_and_b32 %3, %3, %2\n v_and_b32 %5, %5, %4\n v_and_b32 %7, %7, %6" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+        if (WHICH == 14) { REP8(asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1\n v_cvt_pk_bf16_f32 %2, %2, %3\n v_cvt_pk_bf16_f32 %4, %4, %5\n v_cvt_pk_bf16_f32 %6, %6, %7\n v_cvt_pk_bf16_f32 %1, %1, %0\n v_cvt_pk_bf16_f32 %3, %3, %2\n v_cvt_pk_bf16_f32 %5, %5, %4\n v_cvt_pk_bf16_f32 %7, %7, %6" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+        if (WHICH == 15) { REP8(asm volatile("v_perm_b32 %0, %0, %1, %0\n v_perm_b32 %2, %2, %3, %2\n v_perm_b32 %4, %4, %5, %4\n v_perm_b32 %6, %6, %7, %6\n v_perm_b32 %1, %1, %0, %1\n v_perm_b32 %3, %3, %2, %3\n v_perm_b32 %5, %5, %4, %5\n v_perm_b32 %7, %7, %6, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
         if (WHICH == 11) {  // 1 MFMA + 2 exp interleaved
             REP8(c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, h1, c0, 0, 0, 0); asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1" : "+v"(a0), "+v"(a1));
                  c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, h1, c1, 0, 0, 0); asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1" : "+v"(a2), "+v"(a3));
@@ -87,6 +91,10 @@ int main() {
         run<4>("v_cvt_pk_f16_f32", 64, w);
         run<10>("v_cvt_f32_f16", 64, w);
         run<5>("v_fma_mixlo/hi_f16", 64, w);
+        run<12>("v_cvt_pkrtz_f16_f32", 64, w);
+        run<13>("v_and_b32", 64, w);
+        run<14>("v_cvt_pk_bf16_f32", 64, w);
+        run<15>("v_perm_b32", 64, w);
         run<6>("mfma_16x16x32_f16", 64, w);
         run<7>("mfma + 4 v_fma (per 5 inst)", 64 * 5, w);
         run<11>("mfma + 2 v_exp (per 3 inst)", 64 * 3, w);
