@@ -91,6 +91,33 @@ def test_network_pdf_vs_oracle_and_golden(stem, precision):
             rg = _rel(p, g[key])[ok]
             assert np.percentile(rg, 99) < 1e-3
 
+@pytest.mark.parametrize("T", [1, 2, 3, 5, 6, 7, 12, 33])
+@pytest.mark.parametrize("stem", ["chm_orange_rgb_disk", "aniso_miro_7_rgb_spherical"])
+def test_step_counts_incl_non_powers_of_two(stem, T):
+    """T is an argument of the reference operators (mlp_brdf_sampling.py:17); alpha = t/T resp. 1 - t/T is
+    formed in double and cast (the kernel has an exact-fp32 shortcut for powers of two and an fp64 path
+    for the rest).  With T < 4 a single step's det(I + J/T) is ill-conditioned and fp32 arithmetic itself
+    (precision "f32": exact fp32 FMA chains) exceeds 1e-4; there the bound is twice the f32 mode's error."""
+    g, fw = load_case(stem)
+    orc = O.Oracle(fw)
+    xo, po = orc.network_sampling(g["wi"], g["x0"], T)
+    _, acc = orc.flow(g["x0"], g["wi"], T, reverse=False)
+    pro = orc.network_pdf(xo, g["wi"], T)
+    _, accr = orc.flow(xo, g["wi"], T, reverse=True)
+    ok, okr = _resolved(po, acc), _resolved(pro, accr)
+    assert ok.sum() > 1000 and okr.sum() > 1000
+    err = {}
+    for prec in ("f32", "split3"):
+        s = _sampler(fw, prec)
+        x, p = s.network_sampling(_t(g["wi"]), _t(g["x0"]), T=T)
+        x, p = x.cpu().numpy().astype(np.float64), p.cpu().numpy().astype(np.float64)
+        assert np.abs(x - xo).max() < 1e-4
+        pr = s.network_pdf(_t(xo), _t(g["wi"]), T=T).cpu().numpy().astype(np.float64)
+        err[prec] = (np.percentile(_rel(p, po)[ok], 99), np.percentile(_rel(pr, pro)[okr], 99))
+    for k in range(2):
+        bound = 1e-4 if T >= 4 else max(1e-4, 2 * err["f32"][k])
+        assert err["split3"][k] < bound, (T, k, err)
+
 
 @pytest.mark.parametrize("stem", ["aniso_miro_7_rgb_disk", "aniso_miro_7_rgb_spherical",
                                   "aniso_miro_7_rgb_spherical_complex"])
