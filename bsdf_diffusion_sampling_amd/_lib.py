@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("BSDFD_LIB_PATH") or os.path.join(_HERE, "libbsdfd.so")  # override: A/B builds
 SRC_PATH = os.path.join(_HERE, "csrc", "bsdfd.hip")
-SRC_PATHS = [SRC_PATH, os.path.join(_HERE, "csrc", "wavefront.hip"), os.path.join(_HERE, "csrc", "encoding.hip")]  # translation units of libbsdfd.so
+SRC_PATHS = [SRC_PATH, os.path.join(_HERE, "csrc", "wavefront.hip"), os.path.join(_HERE, "csrc", "encoding.hip"),
+             os.path.join(_HERE, "csrc", "measured.hip")]  # translation units of libbsdfd.so
 DEP_PATHS = SRC_PATHS + [os.path.join(_HERE, "csrc", "common.h")]
 INCLUDE_DIR = os.path.join(ROOT, "include")
 
@@ -28,6 +29,7 @@ EXPORTS = (
     "bsdfd_plugin_sample", "bsdfd_plugin_pdf", "bsdfd_plugin_sample_multi", "bsdfd_plugin_pdf_multi",
     "bsdfd_flow_samples_only", "bsdfd_wf_primary", "bsdfd_wf_shade",
     "bsdfd_positional_encoding",
+    "bsdfd_measured_create_from_file", "bsdfd_measured_destroy", "bsdfd_measured_get_info", "bsdfd_measured_eval",
     "bsdfd_set_profiling", "bsdfd_profile_read", "bsdfd_last_kernel_ms", "bsdfd_last_error", "bsdfd_version",
 )
 
@@ -93,8 +95,13 @@ def lib():
     L.bsdfd_plugin_pdf_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, i32, fp, vp]
     L.bsdfd_flow_samples_only.argtypes = [vp, fp, fp, i64, i32, fp, vp]
     L.bsdfd_wf_primary.argtypes = [C.POINTER(WfScene), i32, i32, i32, u64, u64, fp, fp, fp, fp, vp]
-    L.bsdfd_wf_shade.argtypes = [C.POINTER(WfScene), fp, i32, i32, i32, fp, fp, fp, fp, fp, fp, fp, vp]
+    L.bsdfd_wf_shade.argtypes = [C.POINTER(WfScene), fp, i32, i32, i32, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp]
     L.bsdfd_positional_encoding.argtypes = [fp, i64, i32, i32, i32, i32, fp, vp]
+    L.bsdfd_measured_create_from_file.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.bsdfd_measured_destroy.argtypes = [vp]
+    L.bsdfd_measured_destroy.restype = None
+    L.bsdfd_measured_get_info.argtypes = [vp] + [C.POINTER(i32)] * 5
+    L.bsdfd_measured_eval.argtypes = [vp, fp, fp, i64, fp, vp]
     L.bsdfd_set_profiling.argtypes = [vp, i32]
     L.bsdfd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]
     L.bsdfd_last_kernel_ms.argtypes = [vp]

@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, const float* __res
                                                     int row_end, int spp, const float* __restrict__ wo,
                                                     const float* __restrict__ pdf_o, const float* __restrict__ wl,
                                                     const float* __restrict__ pdf_l, const float* __restrict__ nrm,
-                                                    const float* __restrict__ dir, float* __restrict__ film) {
+                                                    const float* __restrict__ dir, const float* __restrict__ f_o,
+                                                    const float* __restrict__ f_l, float* __restrict__ film) {
     const long long npix = (long long)(row_end - row_begin) * sc.width;
     const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= npix) return;
@@ -156,7 +157,9 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, const float* __res
             V3 fs, ft;
             onb(n, fs, ft);
             L[0] = L[1] = L[2] = 0.0f;
-            // BSDF-sampled direction: weight f cos / pdf = albedo (the nets model pdf ∝ lum(f cos))
+            // BSDF-sampled direction: weight f cos / pdf.  With the ground truth (f_o = plugin eval(), which
+            // already carries the albedo tint) that is f_o / pdf; without it the proxy f cos = albedo * pdf
+            // (the nets model pdf ∝ lum(f cos)) gives weight = albedo.
             const V3 o = ld3(wo + 3 * p);
             float pb = pdf_o[p];
             if (!(pb > 0.0f) || !isfinite(pb)) pb = 0.0f;
@@ -165,22 +168,20 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, const float* __res
                 float e[3];
                 env_lookup(env, sc.env_w, sc.env_h, o.x * fs + o.y * ft + o.z * n, e);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) L[c] += w * e[c];
+                for (int c = 0; c < 3; ++c) L[c] += w * e[c] * (f_o ? f_o[3 * p + c] / pb : sc.albedo[c]);
             }
-            // light-sampled direction (cosine hemisphere, pdf cos/pi): f cos / pdf_light = albedo pdf_bsdf / pdf_light
+            // light-sampled direction (cosine hemisphere, pdf cos/pi): f cos / pdf_light
             const V3 l = ld3(wl + 3 * p);
             const float pl = l.z * inv_pi;
             float pbl = pdf_l[p];
             if (!(pbl > 0.0f) || !isfinite(pbl)) pbl = 0.0f;
-            if (pl > 0.0f && pbl > 0.0f) {
-                const float w = mis_power(pl, pbl) * pbl / pl;
+            if (pl > 0.0f && (pbl > 0.0f || f_l)) {
+                const float w = mis_power(pl, pbl) / pl;
                 float e[3];
                 env_lookup(env, sc.env_w, sc.env_h, l.x * fs + l.y * ft + l.z * n, e);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) L[c] += w * e[c];
+                for (int c = 0; c < 3; ++c) L[c] += w * e[c] * (f_l ? f_l[3 * p + c] : sc.albedo[c] * pbl);
             }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) L[c] *= sc.albedo[c];
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc[c] += L[c];
@@ -231,7 +232,7 @@ int bsdfd_wf_primary(const bsdfd_wf_scene* scene, int32_t row_begin, int32_t row
 
 int bsdfd_wf_shade(const bsdfd_wf_scene* scene, const float* env, int32_t row_begin, int32_t row_end, int32_t spp,
                    const float* wo, const float* pdf_o, const float* wl, const float* pdf_l, const float* nrm,
-                   const float* dir, float* film, void* stream) {
+                   const float* dir, const float* f_o, const float* f_l, float* film, void* stream) {
     Scene sc;
     if (int rc = to_scene(scene, row_begin, row_end, spp, sc)) return rc;
     if (sc.env_w <= 0 || sc.env_h <= 0) return bsdfd_fail_(BSDFD_EINVAL, "environment map size must be positive");
@@ -241,7 +242,7 @@ int bsdfd_wf_shade(const bsdfd_wf_scene* scene, const float* env, int32_t row_be
         return bsdfd_fail_(BSDFD_EINVAL, "null pointer");
     const long long blocks = (npix + 255) / 256;
     hipLaunchKernelGGL(shade_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), sc, env,
-                       row_begin, row_end, spp, wo, pdf_o, wl, pdf_l, nrm, dir, film);
+                       row_begin, row_end, spp, wo, pdf_o, wl, pdf_l, nrm, dir, f_o, f_l, film);
     HIP_TRY(hipGetLastError());
     return BSDFD_OK;
 }

@@ -78,7 +78,14 @@ class NeuralBSDFCore:
         self.material = self._material_name()
         self.precision = get("precision", "default")
         self.T = int(get("T", type(self).T))
-        self.bsdf = get("bsdf", None)  # ground-truth evaluator: object with .eval(ctx, si, wo) -> [N,3]
+        # ground-truth evaluator (object with .eval(ctx, si, wo) -> [N,3]): given, or the native RGL
+        # evaluator when measuredbsdfs/<material>.bsdf is found (rendering/brdf_measured_disk.py:36-42)
+        self.bsdf = get("bsdf", None)
+        if self.bsdf is None and get("measured", True):
+            from .measured import MeasuredBSDF, find_measured_file
+            path = get("measured_file", None) or find_measured_file(self._gt_name(), get("measured_dir", None))
+            if path is not None:
+                self.bsdf = MeasuredBSDF(path)
         self.albedo = torch.tensor(get("albedo", [1.0, 1.0, 1.0]), dtype=torch.float32)
         fw = self._load_weights(get("weights", None), get("checkpoint_dir", None))
         self.sampler = FlowSampler(fw, precision=self.precision)
@@ -86,6 +93,10 @@ class NeuralBSDFCore:
     # -- weight discovery ------------------------------------------------
     def _material_name(self) -> str:
         return str(self._get("filename"))
+
+    def _gt_name(self) -> str:
+        """File stem of the ground-truth tensor file (`measuredbsdfs/<stem>.bsdf`)."""
+        return self.material
 
     def _ckpt_tag(self) -> str:
         return self.material

@@ -87,8 +87,14 @@ class WavefrontRenderer:
 
     def __init__(self, plugin, camera: Optional[Camera] = None, env: Optional[torch.Tensor] = None,
                  sphere_center: Sequence[float] = (0.0, 0.0, 0.0), sphere_radius: float = 1.0,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, use_ground_truth: Optional[bool] = None):
         self.plugin = plugin
+        # shade with the ground-truth f (the plugin's native `measured` evaluator) when it is available,
+        # else with the proxy f cos = albedo * pdf_net
+        has_gt = hasattr(getattr(plugin, "bsdf", None), "eval_t")
+        self.use_ground_truth = has_gt if use_ground_truth is None else bool(use_ground_truth)
+        if self.use_ground_truth and not has_gt:
+            raise ValueError("use_ground_truth needs a plugin with a native MeasuredBSDF (props['measured_dir'])")
         self.camera = camera or Camera()
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         env = make_sky() if env is None else env
@@ -114,6 +120,8 @@ class WavefrontRenderer:
         if b is None:
             mk = lambda *shape: torch.empty(shape, dtype=torch.float32, device=self.device)
             b = dict(wi=mk(n, 3), wl=mk(n, 3), nrm=mk(n, 3), dir=mk(n, 3), wo=mk(n, 3), pdf_o=mk(n), pdf_l=mk(n))
+            if self.use_ground_truth:
+                b.update(f_o=mk(n, 3), f_l=mk(n, 3))
             self._buf = {n: b}  # one tile shape at a time
         return b
 
@@ -137,10 +145,12 @@ class WavefrontRenderer:
                 or not film.is_contiguous() or film.device != self.device:
             raise ValueError("film must be a contiguous fp32 [rows, width, 3] tensor on the renderer's device")
         p = lambda t: C.c_void_p(t.data_ptr())
+        f_o = p(b["f_o"]) if "f_o" in b else None
+        f_l = p(b["f_l"]) if "f_l" in b else None
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().bsdfd_wf_shade(C.byref(self.scene), p(self.env), row_begin, row_end, spp,
                                                  p(b["wo"]), p(b["pdf_o"]), p(b["wl"]), p(b["pdf_l"]), p(b["nrm"]),
-                                                 p(b["dir"]), p(film), self._stream()))
+                                                 p(b["dir"]), f_o, f_l, p(film), self._stream()))
 
     # -- one pass over a tile ------------------------------------------------------------------------
     def render_pass(self, film: torch.Tensor, row_begin: int, row_end: int, spp: int, seed: int, pass_idx: int,
@@ -156,6 +166,10 @@ class WavefrontRenderer:
         core.sampler.plugin_sample(b["wi"], x0, T=core.T, variant=core.VARIANT, seed=skey, offset=offset,
                                    out=(b["wo"], b["pdf_o"]))
         core.sampler.plugin_pdf(b["wi"], b["wl"], T=core.T, variant=core.VARIANT, out=b["pdf_l"])
+        if self.use_ground_truth:  # eval() of the reference's loop: f cos (albedo-tinted) for both strategies
+            alb = core.albedo.to(self.device)
+            core.bsdf.eval_t(b["wi"], b["wo"], out=b["f_o"]).mul_(alb)
+            core.bsdf.eval_t(b["wi"], b["wl"], out=b["f_l"]).mul_(alb)
         self.shade(row_begin, row_end, spp, b, film)
 
     def render(self, passes: int, spp: int = 4, seed: int = 0, rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:

@@ -157,6 +157,20 @@ float bsdfd_last_kernel_ms(bsdfd_handle h);
 int bsdfd_positional_encoding(const float* x, int64_t N, int32_t dim, int32_t bands, int32_t include_input,
                               int32_t log_sampling, float* out, void* hip_stream);
 
+/* ---- ground-truth evaluator for eval(): RGL measured BSDF (rgb tensor files) -----------------------
+ * Replaces, for the plugins' eval() / sample-weight / firefly rule, the Mitsuba `measured` BSDF the
+ * reference builds in rendering/brdf_measured_disk.py:36-42 (`mi.load_dict({'type': 'measured',
+ * 'filename': 'measuredbsdfs/<name>.bsdf'})`) and evaluates at :96,107.  Model: Dupuy & Jakob 2018
+ * (csrc/measured.hip).  rgb_out [N,3] = f(wi, wo) * cos(theta_o), 0 where cos(theta_i) <= 0 or
+ * cos(theta_o) <= 0 — Mitsuba's eval() convention. */
+typedef struct bsdfd_measured_ctx* bsdfd_measured_handle;
+int bsdfd_measured_create_from_file(const char* path, bsdfd_measured_handle* out);
+void bsdfd_measured_destroy(bsdfd_measured_handle h);
+int bsdfd_measured_get_info(bsdfd_measured_handle h, int32_t* n_phi, int32_t* n_theta, int32_t* isotropic,
+                            int32_t* jacobian, int32_t* reduction);
+int bsdfd_measured_eval(bsdfd_measured_handle h, const float* wi, const float* wo, int64_t N, float* rgb_out,
+                        void* hip_stream);
+
 /* ---- wavefront harness ------------------------------------
  * The reference renders through Mitsuba 3 (rendering/brdf_measured_disk.py:146-155: passes of
  * `mi.render(scene, spp=4, seed)`), whose integrator calls the plugin's sample()/pdf() once per
@@ -183,10 +197,12 @@ int bsdfd_wf_primary(const bsdfd_wf_scene* scene, int32_t row_begin, int32_t row
                      uint64_t seed, uint64_t pass, float* wi, float* wl, float* nrm, float* dir,
                      void* hip_stream);
 /* One-bounce MIS estimate: wo/pdf_o from plugin sample(), pdf_l = plugin pdf(wi, wl);
- * film [row_end-row_begin, width, 3] += mean over the spp samples of a pixel. */
+ * f_o / f_l [N,3] = plugin eval(wi, wo) / eval(wi, wl) (f cos, albedo included) or both NULL: then the
+ * proxy f cos = albedo * pdf is used.  film [row_end-row_begin, width, 3] += mean over the spp samples. */
 int bsdfd_wf_shade(const bsdfd_wf_scene* scene, const float* env, int32_t row_begin, int32_t row_end,
                    int32_t spp, const float* wo, const float* pdf_o, const float* wl, const float* pdf_l,
-                   const float* nrm, const float* dir, float* film, void* hip_stream);
+                   const float* nrm, const float* dir, const float* f_o, const float* f_l, float* film,
+                   void* hip_stream);
 
 const char* bsdfd_last_error(void);
 const char* bsdfd_version(void);

@@ -130,8 +130,9 @@ def mis_power(pa, pb):
     return np.where(pa > 0, w, 0.0)
 
 
-def shade(scene: dict, env, spp: int, wo, pdf_o, wl, pdf_l, nrm, dir_):
-    """-> per-pixel mean over spp of the one-bounce MIS estimate, [npix, 3] (fp64 accumulation)."""
+def shade(scene: dict, env, spp: int, wo, pdf_o, wl, pdf_l, nrm, dir_, f_o=None, f_l=None):
+    """-> per-pixel mean over spp of the one-bounce MIS estimate, [npix, 3] (fp64 accumulation).
+    f_o / f_l: ground-truth f cos (albedo included) at (wi, wo) / (wi, wl); None -> proxy f cos = albedo pdf."""
     env = env.astype(np.float64)
     n = nrm.astype(np.float64)
     miss = (nrm == 0).all(1)
@@ -142,13 +143,17 @@ def shade(scene: dict, env, spp: int, wo, pdf_o, wl, pdf_l, nrm, dir_):
     inv_pi = 1.0 / np.pi
     pb = np.where(np.isfinite(pdf_o) & (pdf_o > 0), pdf_o, 0.0).astype(np.float64)
     wb = mis_power(pb, np.maximum(wo[:, 2], 0.0).astype(np.float64) * inv_pi)
-    Lb = wb[:, None] * env_lookup(env, to_world(wo.astype(np.float64)).astype(F))
+    albedo = np.asarray(scene["albedo"], dtype=np.float64)[None, :]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        weight_b = albedo if f_o is None else np.where(pb[:, None] > 0, f_o.astype(np.float64) / pb[:, None], 0.0)
+    Lb = wb[:, None] * weight_b * env_lookup(env, to_world(wo.astype(np.float64)).astype(F))
     pl = wl[:, 2].astype(np.float64) * inv_pi
     pbl = np.where(np.isfinite(pdf_l) & (pdf_l > 0), pdf_l, 0.0).astype(np.float64)
-    ok = (pl > 0) & (pbl > 0)
+    ok = (pl > 0) & ((pbl > 0) | (f_l is not None))
     with np.errstate(divide="ignore", invalid="ignore"):
-        wl_w = np.where(ok, mis_power(pl, pbl) * pbl / pl, 0.0)
-    Ll = wl_w[:, None] * env_lookup(env, to_world(wl.astype(np.float64)).astype(F))
-    L = (Lb + Ll) * np.asarray(scene["albedo"], dtype=np.float64)[None, :]
+        wl_w = np.where(ok, mis_power(pl, pbl) / pl, 0.0)
+    weight_l = albedo * pbl[:, None] if f_l is None else f_l.astype(np.float64)
+    Ll = wl_w[:, None] * weight_l * env_lookup(env, to_world(wl.astype(np.float64)).astype(F))
+    L = Lb + Ll
     L = np.where(miss[:, None], env_lookup(env, dir_), L)
     return L.reshape(-1, spp, 3).mean(1)

@@ -1,0 +1,100 @@
+"""GPU: the HIP ground-truth evaluator (csrc/measured.hip) vs oracle/measured_oracle.py, and the plugin's
+eval() / sample-weight / firefly rule running on it (rendering/brdf_measured_disk.py:89-110)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import measured_oracle as M  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+FIXTURE = os.path.join(GOLDEN, "chm_orange_rgb.bsdf")
+
+
+def _dirs(g, n, zmin=0.02):
+    z, ph = g.uniform(zmin, 1.0, size=n), g.uniform(0, 2 * np.pi, size=n)
+    r = np.sqrt(1 - z * z)
+    return np.stack([r * np.cos(ph), r * np.sin(ph), z], 1)
+
+
+def test_eval_matches_oracle():
+    from bsdf_diffusion_sampling_amd.measured import MeasuredBSDF
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    gpu, orc = MeasuredBSDF(FIXTURE), M.MeasuredBSDF(FIXTURE)
+    assert (gpu.n_phi, gpu.n_theta, gpu.isotropic, gpu.jacobian, gpu.reduction) == (1, 8, True, True, 0)
+    g = np.random.default_rng(0)
+    n = 200000
+    wi = _dirs(g, n)
+    wo = _dirs(g, n)
+    # half of the pairs near the specular direction, where the tables are steep
+    k = n // 2
+    wo[:k] = wi[:k] * [-1, -1, 1] + g.normal(size=(k, 3)) * 0.05
+    wo[:k] /= np.linalg.norm(wo[:k], axis=1, keepdims=True)
+    wo[::1000, 2] *= -1                                   # some lower-hemisphere lanes
+    wi32, wo32 = wi.astype(np.float32), wo.astype(np.float32)
+    got = gpu.eval_t(torch.from_numpy(wi32).cuda(), torch.from_numpy(wo32).cuda()).cpu().numpy().astype(np.float64)
+    want = orc.eval(wi32.astype(np.float64), wo32.astype(np.float64))
+    assert np.isfinite(got).all()
+    assert ((got == 0).all(1) == (want == 0).all(1)).all()
+    # fp32 table arithmetic vs fp64: error relative to the lobe's local scale; the NDF is as steep as
+    # d ln D / du ~ 1e3 near the peak, so 1e-7 of coordinate error is 1e-4 of value error
+    scale = np.abs(want).max(1, keepdims=True) + 1e-3
+    err = np.abs(got - want) / scale
+    assert np.percentile(err, 99) < 2e-4 and err.max() < 5e-3, (np.percentile(err, 99), err.max())
+
+
+def test_plugin_uses_native_ground_truth():
+    from bsdf_diffusion_sampling_amd.brdf_measured_disk import MyBSDF
+    from bsdf_diffusion_sampling_amd.plugin_base import SurfaceInteraction, rgb2lum
+    plug = MyBSDF({"filename": "chm_orange_rgb", "measured_dir": GOLDEN, "albedo": [0.9, 0.8, 0.7]})
+    assert plug.bsdf is not None and plug.bsdf.path == FIXTURE
+    none = MyBSDF({"filename": "chm_orange_rgb", "measured": False})
+    assert none.bsdf is None
+    g = np.random.default_rng(1)
+    n = 65536
+    wi = torch.from_numpy(_dirs(g, n, 0.2).astype(np.float32)).cuda()
+    si = SurfaceInteraction(wi)
+    bs, weight = plug.sample(None, si, seed=3)
+    bs0, w0 = none.sample(None, si, seed=3)
+    assert w0 is None and torch.equal(bs0.wo, bs.wo)
+    f = plug.eval(None, si, bs.wo)
+    orc = M.MeasuredBSDF(FIXTURE)
+    f_o = orc.eval(wi.cpu().numpy().astype(np.float64), bs.wo.cpu().numpy().astype(np.float64)) * [0.9, 0.8, 0.7]
+    sc = np.abs(f_o).max(1, keepdims=True) + 1e-3
+    assert np.percentile(np.abs(f.cpu().numpy() - f_o) / sc, 99) < 3e-4
+    # weight = f / pdf with the firefly rule (pdf := 0 where lum(weight) >= 30) and the cos masks
+    raw = f / bs0.pdf[:, None]
+    lum = rgb2lum(raw)
+    fire = lum >= 30
+    assert torch.equal(bs.pdf == 0, (bs0.pdf == 0) | fire)
+    keep = (wi[:, 2] > 0) & (bs.pdf > 0) & (bs.wo[:, 2] > 0)
+    assert torch.allclose(weight[keep], raw[keep], rtol=1e-5, atol=1e-6) and bool((weight[~keep] == 0).all())
+    # importance sampling proportional to lum(f cos): the weights are of order the albedo
+    m = float(rgb2lum(weight[keep]).median())
+    assert 0.1 < m < 1.5, m
+    # eval_pdf = (eval, pdf)
+    e, p = plug.eval_pdf(None, si, bs.wo)
+    assert torch.equal(e, f) and torch.equal(p, plug.pdf(None, si, bs.wo))
+
+
+def test_loader_errors_are_loud(tmp_path):
+    from bsdf_diffusion_sampling_amd.measured import MeasuredBSDF
+    with pytest.raises(RuntimeError, match="cannot open"):
+        MeasuredBSDF(str(tmp_path / "missing.bsdf"))
+    bad = tmp_path / "bad.bsdf"
+    bad.write_bytes(b"not a tensor file at all, definitely")
+    with pytest.raises(RuntimeError, match="not a tensor file"):
+        MeasuredBSDF(str(bad))
+    raw = open(FIXTURE, "rb").read()
+    trunc = tmp_path / "trunc.bsdf"
+    trunc.write_bytes(raw[:100000])
+    with pytest.raises(RuntimeError, match="exceeds the file"):
+        MeasuredBSDF(str(trunc))
+    gpu = MeasuredBSDF(FIXTURE)
+    with pytest.raises(ValueError):
+        gpu.eval_t(torch.zeros(4, 3), torch.zeros(4, 3))
