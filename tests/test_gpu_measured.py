@@ -98,3 +98,25 @@ def test_loader_errors_are_loud(tmp_path):
     gpu = MeasuredBSDF(FIXTURE)
     with pytest.raises(ValueError):
         gpu.eval_t(torch.zeros(4, 3), torch.zeros(4, 3))
+
+
+def test_spherical_plugin_weights_with_native_ground_truth():
+    """rendering/brdf_measured_spherical.py:97-109: value = f * albedo / pdf_sa (0 where inactive or pdf 0),
+    pdf := 0 where lum(value) >= 30, returned weight masked by pdf > 0 and cos(theta_o) > 0."""
+    from bsdf_diffusion_sampling_amd.brdf_measured_spherical import MyBSDF
+    from bsdf_diffusion_sampling_amd.plugin_base import SurfaceInteraction, rgb2lum
+    plug = MyBSDF({"filename": "chm_orange_rgb", "measured_dir": GOLDEN})
+    bare = MyBSDF({"filename": "chm_orange_rgb", "measured": False})
+    g = np.random.default_rng(4)
+    wi = torch.from_numpy(_dirs(g, 32768, 0.2).astype(np.float32)).cuda()
+    si = SurfaceInteraction(wi)
+    bs, weight = plug.sample(None, si, seed=5)
+    bs0, _ = bare.sample(None, si, seed=5)
+    assert torch.equal(bs.wo, bs0.wo)
+    f = plug.eval(None, si, bs.wo)
+    value = torch.where((bs0.pdf > 0)[:, None], f / bs0.pdf[:, None], torch.zeros_like(f))
+    fire = rgb2lum(value) >= 30
+    assert torch.equal(bs.pdf == 0, (bs0.pdf == 0) | fire)
+    keep = (bs.pdf > 0) & (bs.wo[:, 2] > 0)
+    assert torch.allclose(weight[keep], value[keep], rtol=1e-5, atol=1e-6) and bool((weight[~keep] == 0).all())
+    assert torch.isfinite(weight).all() and 0.1 < float(rgb2lum(weight[keep]).median()) < 1.5
