@@ -108,6 +108,10 @@ def test_mixed_material_table_matches_per_material_calls():
     b = tab.sample(ids, wi, seed=11, offset=5, segmented=False)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert torch.equal(tab.pdf(ids, wi, a[0]), tab.pdf(ids, wi, a[0], segmented=False))
+    # a bucketing plan computed once serves both calls
+    plan = tab.bucket(ids)
+    c = tab.sample(plan, wi, seed=11, offset=5)
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and torch.equal(tab.pdf(plan, wi, a[0]), tab.pdf(ids, wi, a[0]))
     # an id with no queries is fine; so is a single-row bucket
     ids2 = torch.zeros(1000, dtype=torch.int64, device=_dev())
     ids2[7] = 2
