@@ -30,6 +30,7 @@ EXPORTS = (
     "bsdfd_flow_samples_only", "bsdfd_wf_primary", "bsdfd_wf_shade",
     "bsdfd_positional_encoding",
     "bsdfd_measured_create_from_file", "bsdfd_measured_destroy", "bsdfd_measured_get_info", "bsdfd_measured_eval",
+    "bsdfd_measured_sample_weight",
     "bsdfd_set_profiling", "bsdfd_profile_read", "bsdfd_last_kernel_ms", "bsdfd_last_error", "bsdfd_version",
 )
 
@@ -101,7 +102,8 @@ def lib():
     L.bsdfd_measured_destroy.argtypes = [vp]
     L.bsdfd_measured_destroy.restype = None
     L.bsdfd_measured_get_info.argtypes = [vp] + [C.POINTER(i32)] * 5
-    L.bsdfd_measured_eval.argtypes = [vp, fp, fp, i64, fp, vp]
+    L.bsdfd_measured_eval.argtypes = [vp, fp, fp, i64, C.POINTER(C.c_float), fp, vp]
+    L.bsdfd_measured_sample_weight.argtypes = [vp, fp, fp, fp, fp, i64, C.POINTER(C.c_float), C.c_float, fp, fp, vp]
     L.bsdfd_set_profiling.argtypes = [vp, i32]
     L.bsdfd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]
     L.bsdfd_last_kernel_ms.argtypes = [vp]

@@ -38,11 +38,15 @@ class MyBSDF(NeuralBSDFCore):
 
     def sample(self, ctx, si, sample1=None, sample2=None, active=True, *, x0=None, seed=None):
         wi = _wi_of(si)
-        act = (wi[:, 2] > 0) if active is True else (torch.as_tensor(active, device=wi.device) & (wi[:, 2] > 0))
         wo, pdf_sa = self.sample_t(wi, x0=x0, seed=seed)
         bs = BSDFSample3f(wo=wo, pdf=pdf_sa, eta=1.0, sampled_type=self.m_flags, sampled_component=0)
         if self.bsdf is None:  # no ground-truth evaluator: the sampler-only use (bench / harness)
             return bs, None
+        if self._native_gt() is not None:  # weight, firefly rule and masks fused into the evaluator's launch
+            weight, bs.pdf = self.bsdf.sample_weight(wi, wo, pdf_sa, tint=self.albedo, firefly_threshold=self.FIREFLY,
+                                                     active=None if active is True else torch.as_tensor(active, device=wi.device))
+            return bs, weight
+        act = (wi[:, 2] > 0) if active is True else (torch.as_tensor(active, device=wi.device) & (wi[:, 2] > 0))
         value = self.eval_unmasked(ctx, si, wo) / pdf_sa[:, None]
         bs.pdf = self.apply_firefly_clamp(pdf_sa, rgb2lum(value), self.FIREFLY)
         keep = act & (bs.pdf > 0) & (wo[:, 2] > 0)

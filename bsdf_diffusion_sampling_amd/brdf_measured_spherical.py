@@ -43,11 +43,15 @@ class MyBSDF(NeuralBSDFCore):
 
     def sample(self, ctx, si, sample1=None, sample2=None, active=True, *, x0=None, seed=None):
         wi = _wi_of(si)
-        act = (wi[:, 2] > 0) if active is True else (torch.as_tensor(active, device=wi.device) & (wi[:, 2] > 0))
         wo, pdf_sa = self.sample_t(wi, x0=x0, seed=seed)
         bs = BSDFSample3f(wo=wo, pdf=pdf_sa, eta=1.0, sampled_type=self.m_flags, sampled_component=0)
         if self.bsdf is None:
             return bs, None
+        if self._native_gt() is not None:  # weight, firefly rule and masks fused into the evaluator's launch
+            weight, bs.pdf = self.bsdf.sample_weight(wi, wo, pdf_sa, tint=self.albedo, firefly_threshold=self.FIREFLY,
+                                                     active=None if active is True else torch.as_tensor(active, device=wi.device))
+            return bs, weight
+        act = (wi[:, 2] > 0) if active is True else (torch.as_tensor(active, device=wi.device) & (wi[:, 2] > 0))
         value = _vec(self._need_bsdf().eval(ctx, si, wo)) * self.albedo.to(wo.device) / pdf_sa[:, None]
         value = torch.where((act & (pdf_sa > 0))[:, None], value, torch.zeros_like(value))  # :105
         bs.pdf = self.apply_firefly_clamp(pdf_sa, rgb2lum(value), self.FIREFLY)

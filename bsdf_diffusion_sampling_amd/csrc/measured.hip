@@ -91,18 +91,11 @@ __device__ __forceinline__ float eval_plain(const Table& t, float x, float y) {
     return bilerp(d[0], d[1], d[t.w], d[t.w + 1], p.fx, p.fy);
 }
 
-__global__ __launch_bounds__(256) void measured_eval_kernel(MeasuredDev m, const float* __restrict__ wi_,
-                                                            const float* __restrict__ wo_, long long n,
-                                                            float* __restrict__ out) {
-    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n) return;
-    float wix = wi_[3 * q], wiy = wi_[3 * q + 1], wiz = wi_[3 * q + 2];
-    float wox = wo_[3 * q], woy = wo_[3 * q + 1], woz = wo_[3 * q + 2];
-    const bool active = wiz > 0.0f && woz > 0.0f;
-    if (!active) {
-        out[3 * q] = out[3 * q + 1] = out[3 * q + 2] = 0.0f;
-        return;
-    }
+// f(wi, wo) cos(theta_o) for one pair; false (and rgb = 0) on the lower hemispheres
+__device__ __forceinline__ bool measured_f(const MeasuredDev& m, float wix, float wiy, float wiz, float wox, float woy,
+                                           float woz, float rgb[3]) {
+    rgb[0] = rgb[1] = rgb[2] = 0.0f;
+    if (!(wiz > 0.0f && woz > 0.0f)) return false;
     if (m.reduction >= 2) {  // mirror symmetries of an anisotropic acquisition
         const float sy = wiy, sx = m.reduction == 4 ? wix : sy;
         if (sx < 0.0f) { wix = -wix; wox = -wox; }
@@ -158,17 +151,60 @@ __global__ __launch_bounds__(256) void measured_eval_kernel(MeasuredDev m, const
     // ---- spectral (rgb) lookup at s ----
     const int sw = m.rgb.w, sh = m.rgb.h;
     const Patch ps = patch_of(s0, s1, sw, sh);
-    float spec[3] = {0.f, 0.f, 0.f};
     for (int k = 0; k < ns; ++k)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float* d = m.rgb.data + (((size_t)slice[k] * 3 + c) * sh + ps.iy) * sw + ps.ix;
-            spec[c] += wgt[k] * bilerp(d[0], d[1], d[sw], d[sw + 1], ps.fx, ps.fy);
+            rgb[c] += wgt[k] * bilerp(d[0], d[1], d[sw], d[sw + 1], ps.fx, ps.fy);
         }
     float scale = 1.0f;
     if (m.jacobian) scale = eval_plain(m.ndf, um_x, um_y) / (4.0f * eval_plain(m.sigma, ui_x, ui_y));
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out[3 * q + c] = spec[c] * scale;
+    for (int c = 0; c < 3; ++c) rgb[c] *= scale;
+    return true;
+}
+
+struct Tint {
+    float r, g, b;
+};
+
+// eval(): rgb_out = f cos * tint
+__global__ __launch_bounds__(256) void measured_eval_kernel(MeasuredDev m, const float* __restrict__ wi,
+                                                            const float* __restrict__ wo, long long n, Tint tint,
+                                                            float* __restrict__ out) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    float f[3];
+    measured_f(m, wi[3 * q], wi[3 * q + 1], wi[3 * q + 2], wo[3 * q], wo[3 * q + 1], wo[3 * q + 2], f);
+    out[3 * q] = f[0] * tint.r; out[3 * q + 1] = f[1] * tint.g; out[3 * q + 2] = f[2] * tint.b;
+}
+
+// The tail of the plugins' sample() in one pass (rendering/brdf_measured_disk.py:89-101,
+// brdf_measured_spherical.py:97-109): value = f * albedo / pdf on active lanes with pdf > 0, firefly rule
+// pdf := 0 where lum(value) >= thr, weight = value where active, pdf > 0 and cos(theta_o) > 0, else 0.
+__global__ __launch_bounds__(256) void measured_weight_kernel(MeasuredDev m, const float* __restrict__ wi,
+                                                              const float* __restrict__ wo,
+                                                              const float* __restrict__ pdf_in,
+                                                              const unsigned char* __restrict__ active, long long n,
+                                                              Tint tint, float thr, float* __restrict__ weight,
+                                                              float* __restrict__ pdf_out) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const float wiz = wi[3 * q + 2], woz = wo[3 * q + 2];
+    float f[3];
+    measured_f(m, wi[3 * q], wi[3 * q + 1], wiz, wo[3 * q], wo[3 * q + 1], woz, f);
+    const float pdf = pdf_in[q];
+    const bool act = wiz > 0.0f && (!active || active[q] != 0);
+    float v[3] = {0.f, 0.f, 0.f};
+    if (act && pdf > 0.0f) {
+        const float inv = 1.0f / pdf;
+        v[0] = f[0] * tint.r * inv; v[1] = f[1] * tint.g * inv; v[2] = f[2] * tint.b * inv;
+    }
+    const float lum = 0.2126f * v[0] + 0.7152f * v[1] + 0.0722f * v[2];  // rendering/utils/mitsuba_brdf_draw.py:36-38
+    const float p = lum < thr ? pdf : 0.0f;
+    const bool keep = act && p > 0.0f && woz > 0.0f;
+    pdf_out[q] = p;
+    weight[3 * q] = keep ? v[0] : 0.0f; weight[3 * q + 1] = keep ? v[1] : 0.0f; weight[3 * q + 2] = keep ? v[2] : 0.0f;
 }
 
 }  // namespace
@@ -350,19 +386,38 @@ int bsdfd_measured_get_info(bsdfd_measured_handle h, int32_t* n_phi, int32_t* n_
     return BSDFD_OK;
 }
 
-int bsdfd_measured_eval(bsdfd_measured_handle h, const float* wi, const float* wo, int64_t n, float* rgb_out,
-                        void* stream) {
+static int measured_launch_checks(bsdfd_measured_handle h, int64_t n) {
     if (!h) return bsdfd_fail_(BSDFD_EINVAL, "null handle");
     if (n < 0) return bsdfd_fail_(BSDFD_EINVAL, "N must be >= 0");
-    if (n == 0) return BSDFD_OK;
-    if (!wi || !wo || !rgb_out) return bsdfd_fail_(BSDFD_EINVAL, "null pointer");
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != h->device) return bsdfd_fail_(BSDFD_EINVAL, "measured handle belongs to another device");
-    const long long blocks = ((long long)n + 255) / 256;
-    if (blocks > 0x7fffffffLL) return bsdfd_fail_(BSDFD_EINVAL, "N too large for one launch");
-    hipLaunchKernelGGL(measured_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       h->dev, wi, wo, (long long)n, rgb_out);
+    if (((long long)n + 255) / 256 > 0x7fffffffLL) return bsdfd_fail_(BSDFD_EINVAL, "N too large for one launch");
+    return BSDFD_OK;
+}
+
+int bsdfd_measured_eval(bsdfd_measured_handle h, const float* wi, const float* wo, int64_t n, const float* tint,
+                        float* rgb_out, void* stream) {
+    if (int rc = measured_launch_checks(h, n)) return rc;
+    if (n == 0) return BSDFD_OK;
+    if (!wi || !wo || !rgb_out) return bsdfd_fail_(BSDFD_EINVAL, "null pointer");
+    const Tint t = tint ? Tint{tint[0], tint[1], tint[2]} : Tint{1.0f, 1.0f, 1.0f};
+    hipLaunchKernelGGL(measured_eval_kernel, dim3((unsigned)(((long long)n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), h->dev, wi, wo, (long long)n, t, rgb_out);
+    HIP_TRY(hipGetLastError());
+    return BSDFD_OK;
+}
+
+int bsdfd_measured_sample_weight(bsdfd_measured_handle h, const float* wi, const float* wo, const float* pdf_sa,
+                                 const unsigned char* active, int64_t n, const float* tint, float firefly_threshold,
+                                 float* weight_out, float* pdf_out, void* stream) {
+    if (int rc = measured_launch_checks(h, n)) return rc;
+    if (n == 0) return BSDFD_OK;
+    if (!wi || !wo || !pdf_sa || !weight_out || !pdf_out) return bsdfd_fail_(BSDFD_EINVAL, "null pointer");
+    const Tint t = tint ? Tint{tint[0], tint[1], tint[2]} : Tint{1.0f, 1.0f, 1.0f};
+    hipLaunchKernelGGL(measured_weight_kernel, dim3((unsigned)(((long long)n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), h->dev, wi, wo, pdf_sa, active, (long long)n, t,
+                       firefly_threshold, weight_out, pdf_out);
     HIP_TRY(hipGetLastError());
     return BSDFD_OK;
 }

@@ -47,19 +47,55 @@ class MeasuredBSDF:
         except Exception:
             pass
 
-    def eval_t(self, wi: torch.Tensor, wo: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        for name, t in (("wi", wi), ("wo", wo)):
-            if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == 3 and t.is_contiguous()):
-                raise ValueError(f"MeasuredBSDF.eval_t: {name} must be a contiguous fp32 CUDA tensor [N,3]")
-        if wi.shape != wo.shape:
-            raise ValueError("MeasuredBSDF.eval_t: wi and wo differ in shape")
+    @staticmethod
+    def _check(**tensors):
+        ref = None
+        for name, (t, cols) in tensors.items():
+            shape_ok = (t.dim() == 2 and t.shape[1] == cols) if cols else t.dim() == 1
+            if not (t.is_cuda and t.dtype == torch.float32 and shape_ok and t.is_contiguous()):
+                raise ValueError(f"MeasuredBSDF: {name} must be a contiguous fp32 CUDA tensor "
+                                 f"[N{',' + str(cols) if cols else ''}]")
+            if ref is not None and t.shape[0] != ref:
+                raise ValueError(f"MeasuredBSDF: {name} has {t.shape[0]} rows, expected {ref}")
+            ref = t.shape[0]
+
+    @staticmethod
+    def _tint(tint):
+        if tint is None:
+            return None
+        vals = [float(v) for v in (tint.tolist() if hasattr(tint, "tolist") else tint)]
+        return (C.c_float * 3)(*vals)
+
+    def eval_t(self, wi: torch.Tensor, wo: torch.Tensor, out: Optional[torch.Tensor] = None, tint=None) -> torch.Tensor:
+        """f(wi, wo) cos(theta_o) [* tint] -> [N,3]; zero on the lower hemispheres."""
+        self._check(wi=(wi, 3), wo=(wo, 3))
         if out is None:
             out = torch.empty_like(wi)
         with torch.cuda.device(wi.device):
             stream = C.c_void_p(torch.cuda.current_stream(wi.device).cuda_stream)
             _lib.check(_lib.lib().bsdfd_measured_eval(self._h, C.c_void_p(wi.data_ptr()), C.c_void_p(wo.data_ptr()),
-                                                      wi.shape[0], C.c_void_p(out.data_ptr()), stream))
+                                                      wi.shape[0], self._tint(tint), C.c_void_p(out.data_ptr()), stream))
         return out
+
+    def sample_weight(self, wi: torch.Tensor, wo: torch.Tensor, pdf_sa: torch.Tensor, tint=None,
+                      firefly_threshold: float = 30.0, active: Optional[torch.Tensor] = None):
+        """The tail of the plugins' sample() in one launch (brdf_measured_disk.py:89-101): -> (weight [N,3],
+        pdf [N]) with value = f * tint / pdf_sa, the firefly rule pdf := 0 where lum(value) >= threshold,
+        and weight = 0 on lanes that are inactive, have pdf 0 or leave through the lower hemisphere."""
+        self._check(wi=(wi, 3), wo=(wo, 3), pdf_sa=(pdf_sa, 0))
+        act = None
+        if active is not None:
+            act = active.to(device=wi.device, dtype=torch.uint8).contiguous()
+            if act.shape != (wi.shape[0],):
+                raise ValueError("MeasuredBSDF.sample_weight: active must be [N]")
+        weight, pdf = torch.empty_like(wi), torch.empty_like(pdf_sa)
+        with torch.cuda.device(wi.device):
+            stream = C.c_void_p(torch.cuda.current_stream(wi.device).cuda_stream)
+            _lib.check(_lib.lib().bsdfd_measured_sample_weight(
+                self._h, C.c_void_p(wi.data_ptr()), C.c_void_p(wo.data_ptr()), C.c_void_p(pdf_sa.data_ptr()),
+                None if act is None else C.c_void_p(act.data_ptr()), wi.shape[0], self._tint(tint),
+                float(firefly_threshold), C.c_void_p(weight.data_ptr()), C.c_void_p(pdf.data_ptr()), stream))
+        return weight, pdf
 
     # the call shape of ``mi.BSDF.eval`` as the reference's plugins use it (brdf_measured_disk.py:96,107)
     def eval(self, ctx, si, wo, active=True):

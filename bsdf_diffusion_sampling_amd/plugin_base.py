@@ -140,8 +140,14 @@ class NeuralBSDFCore:
                                "reference, rendering/brdf_measured_disk.py:36-42); pass props['bsdf']")
         return self.bsdf
 
+    def _native_gt(self):
+        from .measured import MeasuredBSDF
+        return self.bsdf if isinstance(self.bsdf, MeasuredBSDF) else None
+
     def eval(self, ctx, si, wo, active=True):
         wi, wo_t = _wi_of(si), _vec(wo)
+        if self._native_gt() is not None:  # one launch: f cos * albedo, zero on the lower hemispheres
+            return self.bsdf.eval_t(wi, wo_t, tint=self.albedo)
         value = _vec(self._need_bsdf().eval(ctx, si, wo)) * self.albedo.to(wi.device)
         ok = (wi[:, 2] > 0) & (wo_t[:, 2] > 0)
         return torch.where(ok[:, None], value, torch.zeros_like(value))

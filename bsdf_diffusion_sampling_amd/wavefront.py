@@ -167,9 +167,8 @@ class WavefrontRenderer:
                                    out=(b["wo"], b["pdf_o"]))
         core.sampler.plugin_pdf(b["wi"], b["wl"], T=core.T, variant=core.VARIANT, out=b["pdf_l"])
         if self.use_ground_truth:  # eval() of the reference's loop: f cos (albedo-tinted) for both strategies
-            alb = core.albedo.to(self.device)
-            core.bsdf.eval_t(b["wi"], b["wo"], out=b["f_o"]).mul_(alb)
-            core.bsdf.eval_t(b["wi"], b["wl"], out=b["f_l"]).mul_(alb)
+            core.bsdf.eval_t(b["wi"], b["wo"], out=b["f_o"], tint=core.albedo)
+            core.bsdf.eval_t(b["wi"], b["wl"], out=b["f_l"], tint=core.albedo)
         self.shade(row_begin, row_end, spp, b, film)
 
     def render(self, passes: int, spp: int = 4, seed: int = 0, rows: Optional[Tuple[int, int]] = None) -> torch.Tensor:

@@ -168,8 +168,16 @@ int bsdfd_measured_create_from_file(const char* path, bsdfd_measured_handle* out
 void bsdfd_measured_destroy(bsdfd_measured_handle h);
 int bsdfd_measured_get_info(bsdfd_measured_handle h, int32_t* n_phi, int32_t* n_theta, int32_t* isotropic,
                             int32_t* jacobian, int32_t* reduction);
-int bsdfd_measured_eval(bsdfd_measured_handle h, const float* wi, const float* wo, int64_t N, float* rgb_out,
-                        void* hip_stream);
+/* tint: host pointer to 3 floats (the plugin's albedo) or NULL */
+int bsdfd_measured_eval(bsdfd_measured_handle h, const float* wi, const float* wo, int64_t N, const float* tint,
+                        float* rgb_out, void* hip_stream);
+/* The tail of the plugins' sample() in one pass (rendering/brdf_measured_disk.py:89-101,
+ * brdf_measured_spherical.py:97-109): value = f * tint / pdf_sa on active lanes (cos(theta_i) > 0, and
+ * active[q] != 0 if a mask is given) with pdf_sa > 0; firefly rule pdf_out = lum(value) < threshold ? pdf_sa : 0;
+ * weight_out [N,3] = value where active, pdf_out > 0 and cos(theta_o) > 0, else 0. */
+int bsdfd_measured_sample_weight(bsdfd_measured_handle h, const float* wi, const float* wo, const float* pdf_sa,
+                                 const unsigned char* active, int64_t N, const float* tint, float firefly_threshold,
+                                 float* weight_out, float* pdf_out, void* hip_stream);
 
 /* ---- wavefront harness ------------------------------------
  * The reference renders through Mitsuba 3 (rendering/brdf_measured_disk.py:146-155: passes of
