@@ -55,3 +55,8 @@ class MyBSDF(NeuralBSDFCore):
     def eval_unmasked(self, ctx, si, wo):
         from .plugin_base import _vec
         return _vec(self._need_bsdf().eval(ctx, si, wo)) * self.albedo.to(wo.device)
+
+
+if __name__ == "__main__":  # rendering/brdf_measured_disk.py:__main__ — render with this plugin
+    from .render_cli import main
+    main(MyBSDF, "diffusion_brdf_measured_disk/material_ball")

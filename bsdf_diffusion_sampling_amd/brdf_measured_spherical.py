@@ -57,3 +57,8 @@ class MyBSDF(NeuralBSDFCore):
         bs.pdf = self.apply_firefly_clamp(pdf_sa, rgb2lum(value), self.FIREFLY)
         keep = act & (bs.pdf > 0) & (wo[:, 2] > 0)
         return bs, torch.where(keep[:, None], value, torch.zeros_like(value))
+
+
+if __name__ == "__main__":  # rendering/brdf_measured_spherical.py:__main__ — render with this plugin
+    from .render_cli import main
+    main(MyBSDF, "diffusion_brdf_measured_spherical/material_ball")

@@ -107,3 +107,31 @@ def test_camera_basis_and_row_sharding():
     assert rows[0][0] == 0 and rows[-1][1] == 512 and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
     sky = make_sky(32, 64, seed=1)
     assert sky.shape == (32, 64, 3) and bool((sky >= 0).all()) and float(sky.max()) > 1.0
+
+
+def test_png_writer_roundtrip(tmp_path):
+    """render_cli.write_png is the stdlib-only stand-in for mi.util.write_bitmap (brdf_measured_disk.py:158)."""
+    import struct
+    import zlib
+    from bsdf_diffusion_sampling_amd.render_cli import tonemap, write_png
+    g = np.random.default_rng(0)
+    img = g.uniform(0, 4, size=(5, 7, 3))
+    rgb8 = tonemap(img)
+    assert rgb8.dtype == np.uint8 and rgb8.shape == (5, 7, 3) and rgb8.max() <= 255
+    assert (tonemap(np.zeros((1, 1, 3))) == 0).all() and (np.diff(tonemap(np.linspace(0, 10, 50)[None, :, None].repeat(3, 2))[0, :, 0].astype(int)) >= 0).all()
+    p = tmp_path / "x.png"
+    write_png(str(p), rgb8)
+    raw = p.read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, {}
+    while pos < len(raw):
+        n, tag = struct.unpack(">I", raw[pos:pos + 4])[0], raw[pos + 4:pos + 8]
+        data = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + data) & 0xFFFFFFFF
+        chunks[tag] = data
+        pos += 12 + n
+    w, h, depth, ctype = struct.unpack(">IIBB", chunks[b"IHDR"][:10])
+    assert (w, h, depth, ctype) == (7, 5, 8, 2)
+    rows = zlib.decompress(chunks[b"IDAT"])
+    back = np.frombuffer(rows, dtype=np.uint8).reshape(5, 1 + 7 * 3)[:, 1:].reshape(5, 7, 3)
+    assert np.array_equal(back, rgb8)
