@@ -57,7 +57,7 @@ constexpr int PE_SLABS = PE_BANDS + 1;  // K=4 slabs: one per band (sin/cos x 2 
 // inputs (measured: tools/ubench/denorm.hip), so no rescaling is needed and all three products
 // hi*hi + hi*lo + lo*hi accumulate into ONE fp32 accumulator.
 
-enum { OP_SAMPLE = 0, OP_PDF = 1, OP_SAMPLES_ONLY = 2 };
+enum { OP_SAMPLE = 0, OP_PDF = 1, OP_SAMPLES_ONLY = 2, OP_SAMPLE_PDF = 3 };  // 3: plugin io only, sample(wi) then pdf(wi, wl)
 #ifndef BSDFD_TPREC
 #define BSDFD_TPREC 3
 #endif
@@ -84,6 +84,8 @@ struct KParams {
     // multi-material ("segmented") launch: the query arrays hold nseg contiguous buckets, one per
     // material; workgroups [blk_begin, blk_end) of the grid serve bucket [q_begin, q_end) with that
     // material's weight image.  nseg == 0: ordinary single-material launch over [0, N).
+    const float* in_c;   // OP_SAMPLE_PDF: wl [N,3], the direction whose pdf is asked
+    float* out_pdf2;     // OP_SAMPLE_PDF: pdf(wi, wl) [N]
     int chunk_log2;  // a wave takes 2^chunk_log2 consecutive-ish tiles per chunk (see the tile map in the kernel)
     int nseg;
     struct Seg {
@@ -226,7 +228,9 @@ __device__ __forceinline__ float von_mises_sample(float mu, float kappa, unsigne
 //   NH     : number of hidden layers when known at compile time (3 disk, 4 spherical; 32-wide nets: the
 //            layer loop is then fully unrolled — no loop-carried register copies, `last` is static;
 //            measured -3..4 % per Euler step), 0 = run-time p.n_hidden (any depth).
-template <int DOMAIN, int NM, int PREC, bool JAC, int NH>
+//   FUSED  : compiled with the two-phase OP_SAMPLE_PDF loop (its own instantiation: the loop costs the
+//            single-op kernels 2-4 % when compiled into them)
+template <int DOMAIN, int NM, int PREC, bool JAC, int NH, bool FUSED>
 __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // this workgroup's share of the work: the whole batch, or one material's bucket
@@ -282,11 +286,15 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
         zt1c[m] = mfma4(win[m], g == 1 ? 1.0f : 0.0f, zero4);
     }
 
-    const bool reverse = (p.op == OP_PDF);
     const double invT_d = 1.0 / (double)p.T;
     const bool t_pow2 = (p.T & (p.T - 1)) == 0;
     const float invT = (float)invT_d;
-    const float cstep = reverse ? -invT : invT;
+    // OP_SAMPLE_PDF runs the flow twice per query (forward from the base draw, then reverse from wl) on ONE
+    // evaluation of the per-query prologue (encoding, conditioning term, base net): the call pattern of a
+    // renderer that asks sample() and pdf() for the same intersection
+    const int nphase = FUSED ? 2 : 1;
+    const bool reverse1 = (p.op == OP_PDF);  // single-op kernels: fixed for the launch
+    const float cstep1 = reverse1 ? -invT : invT;
     const long long ntiles = (q_end - q_begin + 15) / 16;
 
     // Tile -> wave map: a workgroup takes CHUNKS of 2^cl x waves_per_block consecutive tiles, chunks
@@ -307,7 +315,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 
         // ---------------- inputs: condition (y0,y1) and, for pdf, the outgoing point -------------
         float y0, y1, wi_z = 1.0f;
-        float xs0 = 0.f, xs1 = 0.f, wo_z = 1.0f, wo_sin = 1.0f;
+        float xs0 = 0.f, xs1 = 0.f, wo_z = 1.0f, wo_sin = 1.0f;  // pdf: the point the reverse flow starts from
+        float xi0 = 0.f, xi1 = 0.f;                              // sample: injected x0 (if any)
         if (p.io == IO_OPERATOR) {
             const float2 c2 = reinterpret_cast<const float2*>(p.in_a)[qi];
             y0 = c2.x; y1 = c2.y;
@@ -325,8 +334,9 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                 y0 = acosf(wz / (r + 1e-8f));
                 y1 = atan2f(wy, wx);
             }
-            if (p.op == OP_PDF) {
-                const float ox = p.in_b[qi * 3 + 0], oy = p.in_b[qi * 3 + 1], oz = p.in_b[qi * 3 + 2];
+            if (FUSED || p.op == OP_PDF) {
+                const float* dir = FUSED ? p.in_c : p.in_b;
+                const float ox = dir[qi * 3 + 0], oy = dir[qi * 3 + 1], oz = dir[qi * 3 + 2];
                 wo_z = oz;
                 wo_sin = sqrtf(ox * ox + oy * oy);  // Mitsuba Frame3f::sin_theta
                 if (DOMAIN == BSDFD_DOMAIN_DISK) {
@@ -336,9 +346,10 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                     xs0 = acosf(oz / (r + 1e-8f));
                     xs1 = atan2f(oy, ox);
                 }
-            } else if (p.in_b != nullptr) {
+            }
+            if ((FUSED || p.op != OP_PDF) && p.in_b != nullptr) {  // injected base sample
                 const float2 b2 = reinterpret_cast<const float2*>(p.in_b)[qi];
-                xs0 = b2.x; xs1 = b2.y;
+                if (FUSED) { xi0 = b2.x; xi1 = b2.y; } else { xs0 = b2.x; xs1 = b2.y; }
             }
         }
 
@@ -420,9 +431,16 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
         float kappa = 0.0f;
         if (DOMAIN == BSDFD_DOMAIN_SPHERICAL) kappa = softplus(bo[3]) + 1e-3f;
 
+        int ph = 0;
+    next_phase:  // FUSED: executed twice per tile (a goto, so that the single-op kernels contain no loop at all)
+        {
+        const int op = FUSED ? (ph ? OP_PDF : OP_SAMPLE) : p.op;
+        const bool reverse = FUSED ? (ph != 0) : reverse1;
+        const float cstep = FUSED ? (ph ? -invT : invT) : cstep1;
+        float* const out_pdf = (FUSED && ph) ? p.out_pdf2 : p.out_pdf;
         // ---------------- initial state ------------------------------------------------------------
-        float x0 = xs0, x1 = xs1;
-        if (p.op == OP_SAMPLE && p.in_b == nullptr) {  // draw x0 ~ D_base(. | omega_i) in-kernel
+        float x0 = (FUSED && !ph) ? xi0 : xs0, x1 = (FUSED && !ph) ? xi1 : xs1;
+        if (op == OP_SAMPLE && p.in_b == nullptr) {  // draw x0 ~ D_base(. | omega_i) in-kernel
             const unsigned long long ctr = p.offset + (unsigned long long)qi;
             const unsigned k0 = (unsigned)p.seed, k1 = (unsigned)(p.seed >> 32);
             unsigned u[4];
@@ -462,9 +480,9 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
         };
         float p0 = 1.0f;
 #if (BSDFD_ABL & 8)
-        if (p.op == OP_SAMPLE) p0 = bo[0];
+        if (op == OP_SAMPLE) p0 = bo[0];
 #else
-        if (p.op == OP_SAMPLE) p0 = base_pdf(x0, x1);
+        if (op == OP_SAMPLE) p0 = base_pdf(x0, x1);
 #endif
 
         // ---------------- T explicit Euler steps ---------------------------------------------------
@@ -665,16 +683,16 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 
         // ---------------- epilogue: density, warp, guards, store ------------------------------------
         float pdf = 0.0f;
-        if (p.op == OP_SAMPLE) pdf = p0 * acc;
-        else if (p.op == OP_PDF) pdf = base_pdf(x0, x1) * acc;
+        if (op == OP_SAMPLE) pdf = p0 * acc;
+        else if (op == OP_PDF) pdf = base_pdf(x0, x1) * acc;
 
         const bool writer = valid && g == 0;
         if (p.io == IO_OPERATOR) {
             if (writer) {
-                if (p.op != OP_PDF) reinterpret_cast<float2*>(p.out_x)[qi] = make_float2(x0, x1);
-                if (p.op != OP_SAMPLES_ONLY) p.out_pdf[qi] = pdf;
+                if (op != OP_PDF) reinterpret_cast<float2*>(p.out_x)[qi] = make_float2(x0, x1);
+                if (op != OP_SAMPLES_ONLY) out_pdf[qi] = pdf;
             }
-        } else if (p.op == OP_SAMPLE) {
+        } else if (op == OP_SAMPLE) {
             float ox, oy, oz, pdf_sa;
             if (DOMAIN == BSDFD_DOMAIN_DISK) {  // rendering/brdf_measured_disk.py:69-82
                 const float r2 = x0 * x0 + x1 * x1;
@@ -694,7 +712,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             }
             if (writer) {
                 p.out_x[qi * 3 + 0] = ox; p.out_x[qi * 3 + 1] = oy; p.out_x[qi * 3 + 2] = oz;
-                p.out_pdf[qi] = pdf_sa;
+                out_pdf[qi] = pdf_sa;
             }
         } else {
             float pdf_sa;
@@ -709,8 +727,10 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                     pdf_sa = pdf * inv;
                 }
             }
-            if (writer) p.out_pdf[qi] = pdf_sa;
+            if (writer) out_pdf[qi] = pdf_sa;
         }
+        }
+        if (FUSED && ++ph < nphase) goto next_phase;
     }
 }
 
@@ -731,8 +751,8 @@ int bsdfd_fail_(int code, const std::string& msg) {
 struct bsdfd_ctx {
     int domain, width, n_hidden, precision, state_dim, in_dim;
     int device, num_cu;
-    int per_cu[2];  // resident blocks per CU of the (no-Jacobian, Jacobian) kernel instantiation
-    const void* kfun[2];
+    int per_cu[3];  // resident blocks per CU of the (no-Jacobian, Jacobian, Jacobian + fused sample/pdf) kernels
+    const void* kfun[3];
     ImgLayout L;
     char* d_img;
     // profiling: a ring of HIP event pairs recorded on the launch stream around every launch
@@ -860,29 +880,28 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
 
 // kernel instantiation table: (domain, width/16, precision, Jacobian) x {generic depth, the reference's depths}
 template <int DOMAIN, int NM, int NH>
-const void* kernel_ptr_prec(int prec, bool jac) {
+const void* kernel_ptr_prec(int prec, int mode) {  // mode 0: no Jacobian, 1: Jacobian, 2: Jacobian + fused sample/pdf
+#define BSDFD_K(P, H)                                                                                      \
+    (mode == 0   ? reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, P, false, H, false>)                \
+     : mode == 1 ? reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, P, true, H, false>)                 \
+                 : reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, P, true, H, true>))
     switch (prec) {
-        case BSDFD_PREC_F32:
-            return jac ? reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F32, true, 0>)
-                       : reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F32, false, 0>);
-        case BSDFD_PREC_F16:
-            return jac ? reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F16, true, NH>)
-                       : reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_F16, false, NH>);
-        default:
-            return jac ? reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_SPLIT3, true, NH>)
-                       : reinterpret_cast<const void*>(flow_kernel<DOMAIN, NM, BSDFD_PREC_SPLIT3, false, NH>);
+        case BSDFD_PREC_F32: return BSDFD_K(BSDFD_PREC_F32, 0);
+        case BSDFD_PREC_F16: return BSDFD_K(BSDFD_PREC_F16, NH);
+        default: return BSDFD_K(BSDFD_PREC_SPLIT3, NH);
     }
+#undef BSDFD_K
 }
-const void* kernel_ptr(int domain, int nm, int n_hidden, int prec, bool jac) {
+const void* kernel_ptr(int domain, int nm, int n_hidden, int prec, int mode) {
     if (domain == BSDFD_DOMAIN_DISK) {
-        if (nm == 2) return n_hidden == 3 ? kernel_ptr_prec<BSDFD_DOMAIN_DISK, 2, 3>(prec, jac)
-                                          : kernel_ptr_prec<BSDFD_DOMAIN_DISK, 2, 0>(prec, jac);
-        return kernel_ptr_prec<BSDFD_DOMAIN_DISK, 4, 0>(prec, jac);
+        if (nm == 2) return n_hidden == 3 ? kernel_ptr_prec<BSDFD_DOMAIN_DISK, 2, 3>(prec, mode)
+                                          : kernel_ptr_prec<BSDFD_DOMAIN_DISK, 2, 0>(prec, mode);
+        return kernel_ptr_prec<BSDFD_DOMAIN_DISK, 4, 0>(prec, mode);
     }
-    if (nm == 2) return n_hidden == 4 ? kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 2, 4>(prec, jac)
-                                      : kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 2, 0>(prec, jac);
+    if (nm == 2) return n_hidden == 4 ? kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 2, 4>(prec, mode)
+                                      : kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 2, 0>(prec, mode);
     // the 64-wide nets keep the run-time loop: fully unrolled, 6 layers of 64-wide fragments spill
-    return kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 4, 0>(prec, jac);
+    return kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 4, 0>(prec, mode);
 }
 inline int threads_for(int nm) { return nm == 2 ? 256 : 512; }
 
@@ -905,13 +924,16 @@ struct SegHost {
 };
 
 int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, uint64_t seed, uint64_t offset,
-        int64_t N, int T, float* out_x, float* out_pdf, void* stream, const std::vector<SegHost>* segs = nullptr) {
+        int64_t N, int T, float* out_x, float* out_pdf, void* stream, const std::vector<SegHost>* segs = nullptr,
+        const float* in_c = nullptr, float* out_pdf2 = nullptr) {
     if (!h) return fail(BSDFD_EINVAL, "null handle");
     if (N < 0) return fail(BSDFD_EINVAL, "N must be >= 0");
     if (T < 1 || T > 4096) return fail(BSDFD_EINVAL, "T must be in [1, 4096]");
     if (N == 0) return BSDFD_OK;
     if (!in_a) return fail(BSDFD_EINVAL, "null input pointer");
     if (op == OP_PDF && !in_b) return fail(BSDFD_EINVAL, "pdf needs the outgoing directions");
+    if (op == OP_SAMPLE_PDF && (io == IO_OPERATOR || !in_c || !out_pdf2))
+        return fail(BSDFD_EINVAL, "sample_pdf is a plugin-level call and needs wl and a second pdf output");
     if (op == OP_SAMPLES_ONLY && !in_b) return fail(BSDFD_EINVAL, "flow_samples_only needs x0");
     if (op != OP_PDF && !out_x) return fail(BSDFD_EINVAL, "null output pointer");
     if (op != OP_SAMPLES_ONLY && !out_pdf) return fail(BSDFD_EINVAL, "null pdf output pointer");
@@ -924,6 +946,7 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     KParams kp;
     kp.img = h->d_img; kp.L = h->L;
     kp.in_a = in_a; kp.in_b = in_b; kp.out_x = out_x; kp.out_pdf = out_pdf;
+    kp.in_c = in_c; kp.out_pdf2 = out_pdf2;
     kp.N = N; kp.T = T; kp.n_hidden = h->n_hidden; kp.op = op; kp.io = io; kp.seed = seed; kp.offset = offset;
     kp.nseg = 0;
     kp.chunk_log2 = 3;
@@ -934,8 +957,8 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     // grid: 4 rounds of the resident capacity (blocks per CU from the occupancy query of the
     // instantiated kernel: VGPR- or LDS-limited); block-granular dynamic balancing measured ~4 %
     // faster than an exactly-resident persistent grid (tools/tscan.py sweep)
-    const bool jac = op != OP_SAMPLES_ONLY;
-    int per_cu = h->per_cu[jac ? 1 : 0];
+    const int mode = op == OP_SAMPLES_ONLY ? 0 : (op == OP_SAMPLE_PDF ? 2 : 1);
+    int per_cu = h->per_cu[mode];
     if (per_cu < 1) per_cu = 1;
     static const int per_cu_override = [] {  // tuning knobs (tools/tscan.py, tools/nscan.py), read once
         const char* ov = std::getenv("BSDFD_BLOCKS_PER_CU");
@@ -996,7 +1019,7 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
         HIP_TRY(hipEventRecord(h->ev0[slot], s));
     }
     void* args[] = {const_cast<KParams*>(&kp)};
-    hipError_t e = hipLaunchKernel(h->kfun[jac ? 1 : 0], grid, block, args, (size_t)h->L.total, s);
+    hipError_t e = hipLaunchKernel(h->kfun[mode], grid, block, args, (size_t)h->L.total, s);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) return fail(BSDFD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     if (h->profiling) {
@@ -1080,8 +1103,8 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
         e = hipEventCreate(&h->ev0[i]);
         if (e == hipSuccess) e = hipEventCreate(&h->ev1[i]);
     }
-    for (int jac = 0; jac < 2 && e == hipSuccess; ++jac) {
-        h->kfun[jac] = kernel_ptr(h->domain, h->width / 16, h->n_hidden, prec, jac != 0);
+    for (int jac = 0; jac < 3 && e == hipSuccess; ++jac) {
+        h->kfun[jac] = kernel_ptr(h->domain, h->width / 16, h->n_hidden, prec, jac);
         // dynamic LDS above the default cap needs the attribute (per function and device)
         e = hipFuncSetAttribute(h->kfun[jac], hipFuncAttributeMaxDynamicSharedMemorySize, h->L.total);
         int nb = 0;
@@ -1195,6 +1218,14 @@ int bsdfd_plugin_pdf(bsdfd_handle h, int32_t variant, const float* wi, const flo
         return fail(BSDFD_EINVAL, "unknown plugin variant");
     return run(h, OP_PDF, variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, wo, 0, 0, N, T,
                nullptr, pdf_sa, stream);
+}
+
+int bsdfd_plugin_sample_pdf(bsdfd_handle h, int32_t variant, const float* wi, const float* x0, const float* wl,
+                            uint64_t seed, uint64_t offset, int64_t N, int32_t T, float* wo, float* pdf_wo, float* pdf_wl,
+                            void* stream) {
+    if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE) return fail(BSDFD_EINVAL, "unknown plugin variant");
+    return run(h, OP_SAMPLE_PDF, variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, x0, seed, offset,
+               N, T, wo, pdf_wo, stream, nullptr, wl, pdf_wl);
 }
 
 int bsdfd_plugin_sample_multi(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end, int32_t variant,

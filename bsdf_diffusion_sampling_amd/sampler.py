@@ -145,6 +145,25 @@ class FlowSampler:
                                                    _ptr(wo), _ptr(pdf), self._stream()))
         return wo, pdf
 
+    def plugin_sample_pdf(self, wi, wl, x0=None, T: int = 4, variant: int = _lib.PLUGIN_MEASURED, seed: int = 0,
+                          offset: int = 0, out: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None):
+        """sample(wi) and pdf(wi, wl) of the same intersections in ONE launch (the per-query prologue is
+        shared): -> (wo [N,3], pdf(wo) [N], pdf(wl) [N]), identical to plugin_sample + plugin_pdf(wi, wl)."""
+        wi = self._chk(wi, 3, "wi")
+        n = wi.shape[0]
+        wl = self._chk(wl, 3, "wl", n)
+        x0 = self._chk(x0, 2, "x0", n)
+        if out is None:
+            wo = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+            pdf_o = torch.empty((n,), dtype=torch.float32, device=self.device)
+            pdf_l = torch.empty((n,), dtype=torch.float32, device=self.device)
+        else:
+            wo, pdf_o, pdf_l = self._chk(out[0], 3, "out wo", n), out[1], out[2]
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.bsdfd_plugin_sample_pdf(self._h, variant, _ptr(wi), _ptr(x0), _ptr(wl), seed, offset,
+                                                       n, T, _ptr(wo), _ptr(pdf_o), _ptr(pdf_l), self._stream()))
+        return wo, pdf_o, pdf_l
+
     def plugin_pdf(self, wi, wo, T: int = 4, variant: int = _lib.PLUGIN_MEASURED,
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
         wi = self._chk(wi, 3, "wi")

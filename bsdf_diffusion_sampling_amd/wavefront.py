@@ -13,8 +13,8 @@ per wavefront of (tile pixels x spp) paths per pass, image rows split across GPU
 Per pass and tile (both streaming kernels live in csrc/wavefront.hip, C ABI ``bsdfd_wf_*``):
 
     primary  -> wi, wl (cosine light sample), normal, ray dir      48 B/path written
-    plugin.sample_t(wi)        -> wo, pdf(wo)                      the hot path (fused flow kernel)
-    plugin.pdf_t(wi, wl)       -> pdf(wl)                          the hot path
+    sampler.plugin_sample_pdf(wi, wl) -> wo, pdf(wo), pdf(wl)      the hot path: sample() and pdf() of the
+                                                                   same intersections in one launch
     shade    -> film tile += mean_spp of the MIS estimate          80 B/path read
 
 The ground-truth ``eval()`` of the reference is Mitsuba's ``measured`` BSDF (not neural, not
@@ -163,9 +163,9 @@ class WavefrontRenderer:
         # sample(): Philox counter = global path index, key = (seed, pass) -> independent of the row split
         offset = row_begin * self.camera.width * spp
         skey = (seed * 0x9E3779B97F4A7C15 + pass_idx + 1) & 0xFFFFFFFFFFFFFFFF
-        core.sampler.plugin_sample(b["wi"], x0, T=core.T, variant=core.VARIANT, seed=skey, offset=offset,
-                                   out=(b["wo"], b["pdf_o"]))
-        core.sampler.plugin_pdf(b["wi"], b["wl"], T=core.T, variant=core.VARIANT, out=b["pdf_l"])
+        # one launch for sample(wi) and pdf(wi, wl): the per-intersection prologue is shared
+        core.sampler.plugin_sample_pdf(b["wi"], b["wl"], x0, T=core.T, variant=core.VARIANT, seed=skey, offset=offset,
+                                       out=(b["wo"], b["pdf_o"], b["pdf_l"]))
         if self.use_ground_truth:  # eval() of the reference's loop: f cos (albedo-tinted) for both strategies
             core.bsdf.eval_t(b["wi"], b["wo"], out=b["f_o"], tint=core.albedo)
             core.bsdf.eval_t(b["wi"], b["wl"], out=b["f_l"], tint=core.albedo)

@@ -119,6 +119,15 @@ int bsdfd_plugin_sample(bsdfd_handle h, int32_t variant, const float* wi, const 
 int bsdfd_plugin_pdf(bsdfd_handle h, int32_t variant, const float* wi, const float* wo, int64_t N,
                      int32_t T, float* pdf_sa, void* hip_stream);
 
+/* sample(wi) and pdf(wi, wl) for the SAME intersections in one launch: the per-query prologue
+ * (positional encoding, conditioning term of layer 1, base-density net) is evaluated once and the flow
+ * runs twice (forward from the base draw, reverse from wl).  This is the call pattern of a renderer
+ * with next-event estimation (one sample() and one pdf() per path and bounce); results are identical
+ * to bsdfd_plugin_sample followed by bsdfd_plugin_pdf(wi, wl). */
+int bsdfd_plugin_sample_pdf(bsdfd_handle h, int32_t variant, const float* wi, const float* x0, const float* wl,
+                            uint64_t seed, uint64_t offset, int64_t N, int32_t T, float* wo, float* pdf_wo,
+                            float* pdf_wl, void* hip_stream);
+
 /* Mixed-material batches (BASELINE.json configs[3]; the reference binds one plugin instance per material,
  * rendering/matpreview/disney_bsdf_array0_envmap.xml, and Mitsuba calls each instance on its lanes).
  * The query arrays are BUCKETED by material: bucket i = rows [seg_end[i-1], seg_end[i]) (seg_end is a HOST

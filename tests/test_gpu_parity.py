@@ -389,3 +389,29 @@ def test_extreme_inputs_do_not_crash_and_fail_loudly():
     assert torch.equal(x[keep], ref_x[keep]) and torch.equal(p[keep], ref_p[keep])
     pb = p.cpu().numpy()[[3, 17, 40]]
     assert np.all(~np.isfinite(pb) | (pb == 0))
+
+
+@pytest.mark.parametrize("stem,variant", [("chm_orange_rgb_disk", 0), ("aniso_miro_7_rgb_spherical", 0), ("bsdf_3_spherical", 1)])
+def test_fused_sample_pdf_equals_the_two_calls(stem, variant):
+    """bsdfd_plugin_sample_pdf = plugin_sample(wi) + plugin_pdf(wi, wl) on one evaluation of the prologue."""
+    g, fw = load_case(stem)
+    s = _sampler(fw, "split3")
+    rng = np.random.default_rng(0)
+    n = 30001
+    def dirs(lo):
+        z, ph = rng.uniform(lo, 1.0, size=n), rng.uniform(0, 2 * np.pi, size=n)
+        r = np.sqrt(1 - z * z)
+        return _t(np.stack([r * np.cos(ph), r * np.sin(ph), z], 1))
+    wi, wl = dirs(0.05), dirs(-1.0 if variant else 0.02)
+    T = 4 if fw.domain == 0 else 8
+    for x0 in (None, _t(np.tile(g["x0"], (n // 2048 + 1, 1))[:n])):
+        wo, p = s.plugin_sample(wi, x0, T=T, variant=variant, seed=3, offset=11)
+        pl = s.plugin_pdf(wi, wl, T=T, variant=variant)
+        wo2, p2, pl2 = s.plugin_sample_pdf(wi, wl, x0, T=T, variant=variant, seed=3, offset=11)
+        assert torch.allclose(wo, wo2, rtol=0, atol=2e-6)
+        assert torch.allclose(p, p2, rtol=2e-5, atol=0) and torch.allclose(pl, pl2, rtol=2e-5, atol=0)
+    with pytest.raises(RuntimeError, match="sample_pdf|null|wl"):
+        from bsdf_diffusion_sampling_amd import _lib
+        import ctypes as C
+        _lib.check(_lib.lib().bsdfd_plugin_sample_pdf(s._h, variant, C.c_void_p(wi.data_ptr()), None, None, 0, 0, n, T,
+                                                      C.c_void_p(wo.data_ptr()), C.c_void_p(p.data_ptr()), None, None))
