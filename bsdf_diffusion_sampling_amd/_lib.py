@@ -27,6 +27,7 @@ EXPORTS = (
     "bsdfd_create", "bsdfd_create_from_file", "bsdfd_destroy", "bsdfd_get_info",
     "bsdfd_flops_per_query", "bsdfd_network_sampling", "bsdfd_network_pdf",
     "bsdfd_plugin_sample", "bsdfd_plugin_pdf", "bsdfd_plugin_sample_pdf", "bsdfd_plugin_sample_multi", "bsdfd_plugin_pdf_multi",
+    "bsdfd_plugin_sample_pdf_multi",
     "bsdfd_flow_samples_only", "bsdfd_wf_primary", "bsdfd_wf_shade",
     "bsdfd_positional_encoding",
     "bsdfd_measured_create_from_file", "bsdfd_measured_destroy", "bsdfd_measured_get_info", "bsdfd_measured_eval",
@@ -94,6 +95,7 @@ def lib():
     L.bsdfd_plugin_pdf.argtypes = [vp, i32, fp, fp, i64, i32, fp, vp]
     L.bsdfd_plugin_sample_pdf.argtypes = [vp, i32, fp, fp, fp, u64, u64, i64, i32, fp, fp, fp, vp]
     L.bsdfd_plugin_sample_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, u64, u64, i32, fp, fp, vp]
+    L.bsdfd_plugin_sample_pdf_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, fp, u64, u64, i32, fp, fp, fp, vp]
     L.bsdfd_plugin_pdf_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, i32, fp, vp]
     L.bsdfd_flow_samples_only.argtypes = [vp, fp, fp, i64, i32, fp, vp]
     L.bsdfd_wf_primary.argtypes = [C.POINTER(WfScene), i32, i32, i32, u64, u64, fp, fp, fp, fp, vp]

@@ -1032,7 +1032,8 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
 
 // multi-material launch: all handles must share the kernel signature (domain, width, depth, precision)
 int run_multi(const bsdfd_handle* hs, int n, const int64_t* seg_end, int op, int io, const float* in_a,
-              const float* in_b, uint64_t seed, uint64_t offset, int T, float* out_x, float* out_pdf, void* stream) {
+              const float* in_b, uint64_t seed, uint64_t offset, int T, float* out_x, float* out_pdf, void* stream,
+              const float* in_c = nullptr, float* out_pdf2 = nullptr) {
     if (!hs || !seg_end || n < 1) return fail(BSDFD_EINVAL, "need at least one handle and its segment end");
     for (int i = 0; i < n; ++i) {
         if (!hs[i]) return fail(BSDFD_EINVAL, "null handle in the table");
@@ -1051,7 +1052,7 @@ int run_multi(const bsdfd_handle* hs, int n, const int64_t* seg_end, int op, int
         const long long b = i ? seg_end[i - 1] : 0, e = seg_end[i];
         if (e > b) segs.push_back({hs[i], b, e});
         if ((int)segs.size() == MAX_SEG || (i == n - 1 && !segs.empty())) {
-            rc = run(segs[0].h, op, io, in_a, in_b, seed, offset, N, T, out_x, out_pdf, stream, &segs);
+            rc = run(segs[0].h, op, io, in_a, in_b, seed, offset, N, T, out_x, out_pdf, stream, &segs, in_c, out_pdf2);
             segs.clear();
         }
     }
@@ -1236,6 +1237,15 @@ int bsdfd_plugin_sample_multi(const bsdfd_handle* handles, int32_t n_handles, co
     return run_multi(handles, n_handles, seg_end, OP_SAMPLE,
                      variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, x0, seed, offset, T, wo,
                      pdf_sa, stream);
+}
+
+int bsdfd_plugin_sample_pdf_multi(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end, int32_t variant,
+                                  const float* wi, const float* x0, const float* wl, uint64_t seed, uint64_t offset,
+                                  int32_t T, float* wo, float* pdf_wo, float* pdf_wl, void* stream) {
+    if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE) return fail(BSDFD_EINVAL, "unknown plugin variant");
+    return run_multi(handles, n_handles, seg_end, OP_SAMPLE_PDF,
+                     variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, x0, seed, offset, T, wo,
+                     pdf_wo, stream, wl, pdf_wl);
 }
 
 int bsdfd_plugin_pdf_multi(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end, int32_t variant,

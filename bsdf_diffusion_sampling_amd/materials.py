@@ -95,6 +95,15 @@ class MaterialTable:
                 r = L.bsdfd_plugin_sample_multi(arr_h, k, arr_e, variant, wi_p, x0_p, seed, offset + off_rows, T,
                                                 C.c_void_p(out_wo.data_ptr() + off_rows * 12),
                                                 C.c_void_p(out_pdf.data_ptr() + off_rows * 4), stream)
+            elif which == "sample_pdf":  # aux_s = (x0 or None, wl), out_pdf = (pdf_wo, pdf_wl)
+                x0_s, wl_s = aux_s
+                x0_p = None if x0_s is None else C.c_void_p(x0_s.data_ptr() + off_rows * 8)
+                r = L.bsdfd_plugin_sample_pdf_multi(arr_h, k, arr_e, variant, wi_p, x0_p,
+                                                    C.c_void_p(wl_s.data_ptr() + off_rows * 12), seed,
+                                                    offset + off_rows, T,
+                                                    C.c_void_p(out_wo.data_ptr() + off_rows * 12),
+                                                    C.c_void_p(out_pdf[0].data_ptr() + off_rows * 4),
+                                                    C.c_void_p(out_pdf[1].data_ptr() + off_rows * 4), stream)
             else:
                 r = L.bsdfd_plugin_pdf_multi(arr_h, k, arr_e, variant, wi_p,
                                              C.c_void_p(aux_s.data_ptr() + off_rows * 12), T,
@@ -160,6 +169,27 @@ class MaterialTable:
         wo[perm] = wo_s
         pdf[perm] = pdf_s
         return wo, pdf
+
+    def sample_pdf(self, material_id, wi: torch.Tensor, wl: torch.Tensor, seed: int = 0, offset: int = 0,
+                   T: Optional[int] = None, x0: Optional[torch.Tensor] = None):
+        """sample(wi) and pdf(wi, wl) for the same material-tagged intersections, one launch per kernel
+        signature (``bsdfd_plugin_sample_pdf_multi``) -> (wo [N,3], pdf(wo) [N], pdf(wl) [N]) in the callers' order."""
+        perm, counts = self._buckets(material_id)
+        wi_s, wl_s = wi[perm].contiguous(), wl[perm].contiguous()
+        x0_s = None if x0 is None else x0[perm].contiguous()
+        wo_s = torch.empty_like(wi_s)
+        po_s = torch.empty(wi_s.shape[0], dtype=torch.float32, device=wi.device)
+        pl_s = torch.empty_like(po_s)
+        seg_end = list(__import__("itertools").accumulate(counts))
+        with torch.cuda.device(wi.device):
+            for (dom, w, nh, prec, Tm, var), members in self._groups().items():
+                self._multi("sample_pdf", members, seg_end, Tm if T is None else T, var, wi_s, (x0_s, wl_s), seed,
+                            offset, wo_s, (po_s, pl_s))
+        wo, po, pl = torch.empty_like(wo_s), torch.empty_like(po_s), torch.empty_like(pl_s)
+        wo[perm] = wo_s
+        po[perm] = po_s
+        pl[perm] = pl_s
+        return wo, po, pl
 
     def pdf(self, material_id: torch.Tensor, wi: torch.Tensor, wo: torch.Tensor, T: Optional[int] = None,
             segmented: bool = True):

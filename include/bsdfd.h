@@ -141,6 +141,11 @@ int bsdfd_plugin_sample_multi(const bsdfd_handle* handles, int32_t n_handles, co
 int bsdfd_plugin_pdf_multi(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end,
                            int32_t variant, const float* wi, const float* wo, int32_t T, float* pdf_sa,
                            void* hip_stream);
+/* bsdfd_plugin_sample_pdf over material buckets (same bucket layout as bsdfd_plugin_sample_multi) */
+int bsdfd_plugin_sample_pdf_multi(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end,
+                                  int32_t variant, const float* wi, const float* x0, const float* wl,
+                                  uint64_t seed, uint64_t offset, int32_t T, float* wo, float* pdf_wo,
+                                  float* pdf_wl, void* hip_stream);
 
 /* Reflow teacher sampling without the Jacobian: x <- x + v(x, t/T | omega_i)/T for T steps
  * (learning_repo_cleanup/spherical_domain_sampling.py:147-166, disk_domain_sampling.py:93-110 —

@@ -108,6 +108,11 @@ def test_mixed_material_table_matches_per_material_calls():
     b = tab.sample(ids, wi, seed=11, offset=5, segmented=False)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert torch.equal(tab.pdf(ids, wi, a[0]), tab.pdf(ids, wi, a[0], segmented=False))
+    # sample(wi) + pdf(wi, wl) of the same intersections in one launch per kernel signature
+    wl = _wi("disk", n, 9)
+    wo_f, po_f, pl_f = tab.sample_pdf(ids, wi, wl, seed=11, offset=5)
+    assert torch.allclose(wo_f, a[0], atol=2e-6, rtol=0) and torch.allclose(po_f, a[1], rtol=2e-5, atol=0)
+    assert torch.allclose(pl_f, tab.pdf(ids, wi, wl), rtol=2e-5, atol=0)
     # a bucketing plan computed once serves both calls
     plan = tab.bucket(ids)
     c = tab.sample(plan, wi, seed=11, offset=5)
