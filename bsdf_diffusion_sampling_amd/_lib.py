@@ -14,7 +14,7 @@ ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("BSDFD_LIB_PATH") or os.path.join(_HERE, "libbsdfd.so")  # override: A/B builds
 SRC_PATH = os.path.join(_HERE, "csrc", "bsdfd.hip")
 SRC_PATHS = [SRC_PATH, os.path.join(_HERE, "csrc", "wavefront.hip"), os.path.join(_HERE, "csrc", "encoding.hip"),
-             os.path.join(_HERE, "csrc", "measured.hip")]  # translation units of libbsdfd.so
+             os.path.join(_HERE, "csrc", "measured.hip"), os.path.join(_HERE, "csrc", "bucket.hip")]  # translation units of libbsdfd.so
 DEP_PATHS = SRC_PATHS + [os.path.join(_HERE, "csrc", "common.h")]
 INCLUDE_DIR = os.path.join(ROOT, "include")
 
@@ -29,7 +29,7 @@ EXPORTS = (
     "bsdfd_plugin_sample", "bsdfd_plugin_pdf", "bsdfd_plugin_sample_pdf", "bsdfd_plugin_sample_multi", "bsdfd_plugin_pdf_multi",
     "bsdfd_plugin_sample_pdf_multi",
     "bsdfd_flow_samples_only", "bsdfd_wf_primary", "bsdfd_wf_shade",
-    "bsdfd_positional_encoding",
+    "bsdfd_positional_encoding", "bsdfd_bucket_workspace_bytes", "bsdfd_bucket_by_material",
     "bsdfd_measured_create_from_file", "bsdfd_measured_destroy", "bsdfd_measured_get_info", "bsdfd_measured_eval",
     "bsdfd_measured_sample_weight",
     "bsdfd_set_profiling", "bsdfd_profile_read", "bsdfd_last_kernel_ms", "bsdfd_last_error", "bsdfd_version",
@@ -107,6 +107,9 @@ def lib():
     L.bsdfd_measured_get_info.argtypes = [vp] + [C.POINTER(i32)] * 5
     L.bsdfd_measured_eval.argtypes = [vp, fp, fp, i64, C.POINTER(C.c_float), fp, vp]
     L.bsdfd_measured_sample_weight.argtypes = [vp, fp, fp, fp, fp, i64, C.POINTER(C.c_float), C.c_float, fp, fp, vp]
+    L.bsdfd_bucket_workspace_bytes.argtypes = [i64, i32]
+    L.bsdfd_bucket_workspace_bytes.restype = i64
+    L.bsdfd_bucket_by_material.argtypes = [fp, i64, i32, fp, fp, fp, i64, vp]
     L.bsdfd_set_profiling.argtypes = [vp, i32]
     L.bsdfd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]
     L.bsdfd_last_kernel_ms.argtypes = [vp]

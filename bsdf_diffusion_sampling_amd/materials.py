@@ -129,7 +129,10 @@ class MaterialTable:
         if material_id.dtype != torch.int64:
             material_id = material_id.long()
         perm, counts = bucket_by_material(material_id, len(self))
-        return perm, counts.cpu().tolist()
+        counts = counts.cpu().tolist()
+        if sum(counts) != material_id.shape[0]:
+            raise ValueError(f"material ids must be in [0, {len(self)})")
+        return perm, counts
 
     def bucket(self, material_id: torch.Tensor):
         """Bucket a wavefront once and reuse the plan for its sample() and pdf() calls (a renderer asks both

@@ -171,6 +171,15 @@ float bsdfd_last_kernel_ms(bsdfd_handle h);
 int bsdfd_positional_encoding(const float* x, int64_t N, int32_t dim, int32_t bands, int32_t include_input,
                               int32_t log_sampling, float* out, void* hip_stream);
 
+/* ---- bucketing of a material-tagged wavefront (config 4) ---------------------------------------------
+ * Stable counting sort of N lanes by material id (int64, 0 <= id < n_materials <= 64), on the device:
+ * perm [N] gathers lanes into bucket order (torch.argsort(stable=True) semantics), counts [n_materials]
+ * are the bucket sizes (device memory).  `workspace`: device scratch of bsdfd_bucket_workspace_bytes().
+ * Lanes with an id outside the range are left out of perm (counts then sum to less than N). */
+int64_t bsdfd_bucket_workspace_bytes(int64_t N, int32_t n_materials);
+int bsdfd_bucket_by_material(const int64_t* material_id, int64_t N, int32_t n_materials, int64_t* perm,
+                             int64_t* counts, void* workspace, int64_t workspace_bytes, void* hip_stream);
+
 /* ---- ground-truth evaluator for eval(): RGL measured BSDF (rgb tensor files) -----------------------
  * Replaces, for the plugins' eval() / sample-weight / firefly rule, the Mitsuba `measured` BSDF the
  * reference builds in rendering/brdf_measured_disk.py:36-42 (`mi.load_dict({'type': 'measured',

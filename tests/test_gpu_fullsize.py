@@ -212,3 +212,29 @@ def test_every_shipped_material_matches_the_oracle():
             s.close()
     w = max(worst.items(), key=lambda kv: kv[1][0])
     print("worst p99 pdf rel-err:", w)
+
+
+@pytest.mark.parametrize("n,m", [(0, 3), (1, 1), (4095, 5), (4096, 64), (4097, 52), (1 << 20, 52), (3_000_001, 7)])
+def test_native_bucketing_equals_stable_argsort(n, m):
+    """csrc/bucket.hip: the stable counting sort reproduces torch.argsort(stable=True) + bincount exactly."""
+    from bsdf_diffusion_sampling_amd.sharding import bucket_by_material
+    ids = torch.randint(0, m, (n,), generator=torch.Generator().manual_seed(n + m))
+    if n > 10:
+        ids[: n // 3] = m - 1                       # a long run and an empty-ish tail of bins
+    perm, counts = bucket_by_material(ids.to(_dev()), m)
+    assert perm.dtype == torch.int64 and counts.dtype == torch.int64
+    assert torch.equal(counts.cpu(), torch.bincount(ids, minlength=m))
+    assert torch.equal(perm.cpu(), torch.argsort(ids, stable=True))
+
+
+def test_bucketing_rejects_bad_ids_and_sizes():
+    from bsdf_diffusion_sampling_amd.materials import MaterialTable
+    from bsdf_diffusion_sampling_amd.sharding import bucket_by_material
+    tab = MaterialTable(["aniso_miro_7_rgb_disk", "chm_orange_rgb_disk"])
+    ids = torch.tensor([0, 1, 2, 0], device=_dev())
+    with pytest.raises(ValueError, match="material ids"):
+        tab.bucket(ids)
+    # more than 64 materials: torch path, same contract
+    big = torch.randint(0, 100, (5000,), generator=torch.Generator().manual_seed(0)).to(_dev())
+    perm, counts = bucket_by_material(big, 100)
+    assert torch.equal(perm.cpu(), torch.argsort(big.cpu(), stable=True)) and int(counts.sum()) == 5000
