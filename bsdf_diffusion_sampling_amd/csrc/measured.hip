@@ -39,6 +39,7 @@ struct MeasuredDev {
     const float* theta_i;
     int n_phi, n_theta;
     int isotropic, jacobian, reduction;
+    float fold_x, fold_y;  // signs of (cos, sin) at the middle of the file's phi_i range: the quadrant / half-plane stored
     Table ndf, sigma, vndf, rgb;
     const float* vndf_cond;  // [n_phi][n_theta][h][w]  cumulative row integrals (patch units, normalised)
     const float* vndf_marg;  // [n_phi][n_theta][h]
@@ -96,10 +97,15 @@ __device__ __forceinline__ bool measured_f(const MeasuredDev& m, float wix, floa
                                            float woz, float rgb[3]) {
     rgb[0] = rgb[1] = rgb[2] = 0.0f;
     if (!(wiz > 0.0f && woz > 0.0f)) return false;
-    if (m.reduction >= 2) {  // mirror symmetries of an anisotropic acquisition
-        const float sy = wiy, sx = m.reduction == 4 ? wix : sy;
-        if (sx < 0.0f) { wix = -wix; wox = -wox; }
-        if (sy < 0.0f) { wiy = -wiy; woy = -woy; }
+    if (m.reduction >= 2) {
+        // Symmetries of an anisotropic acquisition: only phi_i in a half-plane (reduction 2: point symmetry)
+        // or a quadrant (reduction 4: two mirror planes) is stored.  Mitsuba folds with mulsign_neg(v, s) =
+        // -|..|, i.e. into y <= 0 (and x <= 0), which is where its files keep phi_i; here the target is read
+        // off the file's own phi_i range, which is the same thing for such files and right for any other.
+        const bool fy = wiy * m.fold_y < 0.0f;
+        const bool fx = m.reduction == 4 ? (wix * m.fold_x < 0.0f) : fy;
+        if (fx) { wix = -wix; wox = -wox; }
+        if (fy) { wiy = -wiy; woy = -woy; }
     }
     float mx = wix + wox, my = wiy + woy, mz = wiz + woz;
     const float inv = 1.0f / fmaxf(sqrtf(mx * mx + my * my + mz * mz), 1e-30f);
@@ -313,7 +319,13 @@ int bsdfd_measured_create_from_file(const char* path, bsdfd_measured_handle* out
     d.jacobian = jac->ptr[0] ? 1 : 0;
     d.reduction = 0;
     const std::vector<float> phi_v = as_f32(*phi), theta_v = as_f32(*theta);
-    if (!d.isotropic) d.reduction = (int)std::lrint(2.0 * M_PI / ((double)phi_v[n_phi - 1] - (double)phi_v[0]));
+    d.fold_x = d.fold_y = 1.0f;
+    if (!d.isotropic) {
+        d.reduction = (int)std::lrint(2.0 * M_PI / ((double)phi_v[n_phi - 1] - (double)phi_v[0]));
+        const double mid = 0.5 * ((double)phi_v[0] + (double)phi_v[n_phi - 1]);
+        d.fold_x = std::cos(mid) < 0.0 ? -1.0f : 1.0f;
+        d.fold_y = std::sin(mid) < 0.0 ? -1.0f : 1.0f;
+    }
 
     // VNDF: per-slice normalisation and CDFs in double.  Integrals in patch units: a linear segment
     // integrates to the mean of its end points, a row of patches to the mean of its two vertex rows.

@@ -204,6 +204,8 @@ class MeasuredBSDF:
         self.reduction = 0
         if not self.isotropic:
             self.reduction = int(np.rint(2 * np.pi / (phi_i[-1] - phi_i[0])))
+            mid = 0.5 * (phi_i[0] + phi_i[-1])
+            self.fold = (-1.0 if np.cos(mid) < 0 else 1.0, -1.0 if np.sin(mid) < 0 else 1.0)
         self.ndf = Marginal2D(t["ndf"], (), normalize=False, sampling=False)
         self.sigma = Marginal2D(t["sigma"], (), normalize=False, sampling=False)
         self.vndf = Marginal2D(t["vndf"], (phi_i, theta_i), normalize=True, sampling=True)
@@ -213,12 +215,15 @@ class MeasuredBSDF:
         """wi, wo [N,3] unit vectors in the local frame -> f(wi, wo) cos(theta_o), [N,3] rgb."""
         wi, wo = np.asarray(wi, dtype=np.float64).copy(), np.asarray(wo, dtype=np.float64).copy()
         active = (wi[:, 2] > 0) & (wo[:, 2] > 0)
-        if self.reduction >= 2:  # mirror symmetries of an anisotropic acquisition (untested: no such file here)
-            sy = wi[:, 1].copy()
-            sx = wi[:, 0].copy() if self.reduction == 4 else sy
+        if self.reduction >= 2:
+            # only phi_i in a half-plane (reduction 2) or quadrant (reduction 4) is stored; Mitsuba folds with
+            # mulsign_neg into y <= 0 (x <= 0), where its files keep phi_i — here the target quadrant is read
+            # off the file's phi_i range (untested against a real anisotropic file: none ships with the reference)
+            fy = wi[:, 1] * self.fold[1] < 0
+            fx = (wi[:, 0] * self.fold[0] < 0) if self.reduction == 4 else fy
             for v in (wi, wo):
-                v[:, 0] = np.where(sx < 0, -v[:, 0], v[:, 0])
-                v[:, 1] = np.where(sy < 0, -v[:, 1], v[:, 1])
+                v[:, 0] = np.where(fx, -v[:, 0], v[:, 0])
+                v[:, 1] = np.where(fy, -v[:, 1], v[:, 1])
         wm = wi + wo
         wm /= np.maximum(np.linalg.norm(wm, axis=1, keepdims=True), 1e-30)
         theta_i, phi_i = elevation(wi), np.arctan2(wi[:, 1], wi[:, 0])

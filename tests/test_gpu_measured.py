@@ -150,7 +150,7 @@ def test_anisotropic_branch_is_self_consistent(tmp_path):
         for ax in (-1, -2):
             a = (a + np.roll(a, 1, axis=ax) + np.roll(a, -1, axis=ax)) / 3
         return a.astype(np.float32)
-    phi_i = np.linspace(0.0, np.pi / 2, 4).astype(np.float32)          # reduction = rint(2 pi / (pi/2)) = 4
+    phi_i = np.linspace(-np.pi, -np.pi / 2, 4).astype(np.float32)     # Mitsuba's quadrant; reduction = rint(2 pi / (pi/2)) = 4
     theta_i = np.linspace(0.0, np.pi / 2, 5).astype(np.float32)
     fields = {"version": np.array([1, 0], dtype=np.uint8), "description": np.frombuffer(b"synthetic anisotropic", dtype=np.uint8),
               "phi_i": phi_i, "theta_i": theta_i, "sigma": smooth(9, 17), "ndf": smooth(9, 17) * 3,
@@ -169,6 +169,12 @@ def test_anisotropic_branch_is_self_consistent(tmp_path):
     err = np.abs(got - want) / (np.abs(want).max(1, keepdims=True) + 1e-3)
     assert np.percentile(err, 99) < 1e-4 and err.max() < 2e-3, (np.percentile(err, 99), err.max())
     # the reduction folds the azimuth quadrants: mirrored pairs evaluate identically
-    flip = np.array([-1.0, 1.0, 1.0], dtype=np.float32)
-    got_m = gpu.eval_t(torch.from_numpy(wi * flip).cuda(), torch.from_numpy(wo * flip).cuda()).cpu().numpy()
-    assert np.allclose(got_m, got, rtol=1e-4, atol=1e-5)
+    for flip in ([-1.0, 1.0, 1.0], [1.0, -1.0, 1.0], [-1.0, -1.0, 1.0]):
+        f = np.array(flip, dtype=np.float32)
+        got_m = gpu.eval_t(torch.from_numpy(wi * f).cuda(), torch.from_numpy(wo * f).cuda()).cpu().numpy()
+        assert np.allclose(got_m, got, rtol=1e-4, atol=1e-5)
+    # every folded incident direction lands inside the stored phi_i range
+    w = wi.astype(np.float64).copy()
+    w[:, 0] = -np.abs(w[:, 0]); w[:, 1] = -np.abs(w[:, 1])
+    ph = np.arctan2(w[:, 1], w[:, 0])
+    assert (ph >= phi_i[0] - 1e-6).all() and (ph <= phi_i[-1] + 1e-6).all()
