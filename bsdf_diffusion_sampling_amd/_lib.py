@@ -41,7 +41,10 @@ class WfScene(C.Structure):
     _fields_ = [("cam_origin", C.c_float * 3), ("cam_right", C.c_float * 3), ("cam_up", C.c_float * 3),
                 ("cam_forward", C.c_float * 3), ("tan_half_fov", C.c_float), ("width", C.c_int32),
                 ("height", C.c_int32), ("sphere_center", C.c_float * 3), ("sphere_radius", C.c_float),
-                ("albedo", C.c_float * 3), ("env_width", C.c_int32), ("env_height", C.c_int32)]
+                ("albedo", C.c_float * 3), ("env_width", C.c_int32), ("env_height", C.c_int32),
+                ("n_extra_spheres", C.c_int32), ("extra_spheres", (C.c_float * 4) * 31), ("has_plane", C.c_int32),
+                ("plane_y", C.c_float), ("checker_scale", C.c_float), ("checker_color0", C.c_float),
+                ("checker_color1", C.c_float)]
 
 
 class Desc(C.Structure):
@@ -98,8 +101,8 @@ def lib():
     L.bsdfd_plugin_sample_pdf_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, fp, u64, u64, i32, fp, fp, fp, vp]
     L.bsdfd_plugin_pdf_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, i32, fp, vp]
     L.bsdfd_flow_samples_only.argtypes = [vp, fp, fp, i64, i32, fp, vp]
-    L.bsdfd_wf_primary.argtypes = [C.POINTER(WfScene), i32, i32, i32, u64, u64, fp, fp, fp, fp, vp]
-    L.bsdfd_wf_shade.argtypes = [C.POINTER(WfScene), fp, i32, i32, i32, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp]
+    L.bsdfd_wf_primary.argtypes = [C.POINTER(WfScene), i32, i32, i32, u64, u64, fp, fp, fp, fp, fp, vp]
+    L.bsdfd_wf_shade.argtypes = [C.POINTER(WfScene), fp, i32, i32, i32, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp]
     L.bsdfd_positional_encoding.argtypes = [fp, i64, i32, i32, i32, i32, fp, vp]
     L.bsdfd_measured_create_from_file.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.bsdfd_measured_destroy.argtypes = [vp]

@@ -50,18 +50,25 @@ __device__ __forceinline__ void onb(V3 n, V3& s, V3& t) {
     t = v3(b, sign + n.y * n.y * a, -n.y);
 }
 
+constexpr int WF_MAX_SPHERES = 32;
+
 struct Scene {
-    V3 o, right, up, fwd, c;
-    float tan_half_fov, radius;
+    V3 o, right, up, fwd;
+    float tan_half_fov;
     int width, height;
     float albedo[3];
     int env_w, env_h;
+    int n_sph;                       // material balls; ball k carries material k
+    float sph[WF_MAX_SPHERES][4];    // centre xyz, radius
+    int has_plane;                   // diffuse checkerboard ground plane y = plane_y (the matpreview scenes' floor)
+    float plane_y, checker_scale, checker_c0, checker_c1;
 };
 
 __global__ __launch_bounds__(256) void primary_kernel(Scene sc, int row_begin, int row_end, int spp,
                                                       unsigned long long seed, unsigned long long pass,
                                                       float* __restrict__ wi, float* __restrict__ wl,
-                                                      float* __restrict__ nrm, float* __restrict__ dir) {
+                                                      float* __restrict__ nrm, float* __restrict__ dir,
+                                                      long long* __restrict__ mat) {
     const long long n = (long long)(row_end - row_begin) * sc.width * spp;
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -80,20 +87,39 @@ __global__ __launch_bounds__(256) void primary_kernel(Scene sc, int row_begin, i
     const float sy = (1.0f - 2.0f * fy) * sc.tan_half_fov * ((float)sc.height / (float)sc.width);
     V3 d = sc.fwd + sx * sc.right + sy * sc.up;
     d = (1.0f / sqrtf(dot(d, d))) * d;
-    // analytic sphere
-    const V3 oc = sc.o - sc.c;
-    const float b = dot(oc, d);
-    const V3 perp = oc - b * d;  // discriminant as R^2 - (distance of the centre from the ray)^2: no b^2 - c cancellation
-    const float disc = sc.radius * sc.radius - dot(perp, perp);
-    const float t = -b - sqrtf(fmaxf(disc, 0.0f));
-    const bool hit = disc > 0.0f && t > 0.0f;
+    // closest hit among the analytic balls and the ground plane
+    float t_best = 3.0e38f;
+    int hit_k = -1;
+    for (int k = 0; k < sc.n_sph; ++k) {
+        const V3 oc = sc.o - v3(sc.sph[k][0], sc.sph[k][1], sc.sph[k][2]);
+        const float b = dot(oc, d);
+        const V3 perp = oc - b * d;  // discriminant as R^2 - (distance of the centre from the ray)^2: no b^2 - c cancellation
+        const float disc = sc.sph[k][3] * sc.sph[k][3] - dot(perp, perp);
+        const float t = -b - sqrtf(fmaxf(disc, 0.0f));
+        if (disc > 0.0f && t > 0.0f && t < t_best) { t_best = t; hit_k = k; }
+    }
+    bool plane = false;
+    if (sc.has_plane && d.y < 0.0f) {
+        const float t = (sc.plane_y - sc.o.y) / d.y;
+        if (t > 0.0f && t < t_best) { t_best = t; plane = true; hit_k = -1; }
+    }
     V3 nn = v3(0.f, 0.f, 0.f), w_in = v3(0.f, 0.f, 1.f);
-    if (hit) {
-        nn = (1.0f / sc.radius) * (oc + t * d);
+    long long material = sc.n_sph + 1;  // miss
+    if (hit_k >= 0) {
+        const V3 oc = sc.o - v3(sc.sph[hit_k][0], sc.sph[hit_k][1], sc.sph[hit_k][2]);
+        nn = (1.0f / sc.sph[hit_k][3]) * (oc + t_best * d);
         nn = (1.0f / sqrtf(dot(nn, nn))) * nn;
         V3 fs, ft;
         onb(nn, fs, ft);
         w_in = v3(-dot(d, fs), -dot(d, ft), -dot(d, nn));
+        material = hit_k;
+    } else if (plane) {  // the floor is not neural: its reflectance travels in the wi slot, its id is n_sph
+        const V3 h = sc.o + t_best * d;
+        const int cx = (int)floorf(h.x * sc.checker_scale), cz = (int)floorf(h.z * sc.checker_scale);
+        const float refl = ((cx + cz) & 1) ? sc.checker_c1 : sc.checker_c0;
+        nn = v3(0.f, 1.f, 0.f);
+        w_in = v3(refl, refl, refl);
+        material = sc.n_sph;
     }
     // cosine-weighted light-sample direction in the local frame
     const float u2 = u01_open(u[2]), u3 = (float)(u[3] >> 8) * (1.0f / 16777216.0f);
@@ -105,6 +131,7 @@ __global__ __launch_bounds__(256) void primary_kernel(Scene sc, int row_begin, i
     st3(wl + 3 * p, w_l);
     st3(nrm + 3 * p, nn);
     st3(dir + 3 * p, d);
+    if (mat) mat[p] = material;
 }
 
 // lat-long radiance map, y up: u = atan2(x, -z) / 2pi (wrapped), v = acos(y) / pi; bilinear
@@ -141,7 +168,8 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, const float* __res
                                                     const float* __restrict__ pdf_o, const float* __restrict__ wl,
                                                     const float* __restrict__ pdf_l, const float* __restrict__ nrm,
                                                     const float* __restrict__ dir, const float* __restrict__ f_o,
-                                                    const float* __restrict__ f_l, float* __restrict__ film) {
+                                                    const float* __restrict__ f_l, const float* __restrict__ wi,
+                                                    const long long* __restrict__ mat, float* __restrict__ film) {
     const long long npix = (long long)(row_end - row_begin) * sc.width;
     const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (pix >= npix) return;
@@ -153,6 +181,15 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, const float* __res
         float L[3];
         if (n.x == 0.0f && n.y == 0.0f && n.z == 0.0f) {  // miss: the camera sees the environment
             env_lookup(env, sc.env_w, sc.env_h, ld3(dir + 3 * p), L);
+        } else if (mat && mat[p] == sc.n_sph) {  // diffuse floor, cosine-sampled: f cos / pdf = reflectance
+            V3 fs, ft;
+            onb(n, fs, ft);
+            const V3 l = ld3(wl + 3 * p);
+            float e[3];
+            env_lookup(env, sc.env_w, sc.env_h, l.x * fs + l.y * ft + l.z * n, e);
+            const float refl = wi[3 * p];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) L[c] = refl * e[c];
         } else {
             V3 fs, ft;
             onb(n, fs, ft);
@@ -198,16 +235,26 @@ int to_scene(const bsdfd_wf_scene* s, int row_begin, int row_end, int spp, Scene
         return bsdfd_fail_(BSDFD_EINVAL, "row range outside the film");
     if (spp <= 0) return bsdfd_fail_(BSDFD_EINVAL, "spp must be positive");
     if (!(s->sphere_radius > 0.0f)) return bsdfd_fail_(BSDFD_EINVAL, "sphere radius must be positive");
+    if (s->n_extra_spheres < 0 || s->n_extra_spheres > WF_MAX_SPHERES - 1)
+        return bsdfd_fail_(BSDFD_EINVAL, "at most 31 extra spheres");
     sc.o = v3(s->cam_origin[0], s->cam_origin[1], s->cam_origin[2]);
     sc.right = v3(s->cam_right[0], s->cam_right[1], s->cam_right[2]);
     sc.up = v3(s->cam_up[0], s->cam_up[1], s->cam_up[2]);
     sc.fwd = v3(s->cam_forward[0], s->cam_forward[1], s->cam_forward[2]);
-    sc.c = v3(s->sphere_center[0], s->sphere_center[1], s->sphere_center[2]);
     sc.tan_half_fov = s->tan_half_fov;
-    sc.radius = s->sphere_radius;
     sc.width = s->width; sc.height = s->height;
     for (int c = 0; c < 3; ++c) sc.albedo[c] = s->albedo[c];
     sc.env_w = s->env_width; sc.env_h = s->env_height;
+    sc.n_sph = 1 + s->n_extra_spheres;
+    for (int c = 0; c < 3; ++c) sc.sph[0][c] = s->sphere_center[c];
+    sc.sph[0][3] = s->sphere_radius;
+    for (int k = 0; k < s->n_extra_spheres; ++k) {
+        if (!(s->extra_spheres[k][3] > 0.0f)) return bsdfd_fail_(BSDFD_EINVAL, "sphere radius must be positive");
+        for (int c = 0; c < 4; ++c) sc.sph[k + 1][c] = s->extra_spheres[k][c];
+    }
+    sc.has_plane = s->has_plane ? 1 : 0;
+    sc.plane_y = s->plane_y; sc.checker_scale = s->checker_scale;
+    sc.checker_c0 = s->checker_color0; sc.checker_c1 = s->checker_color1;
     return BSDFD_OK;
 }
 
@@ -216,7 +263,7 @@ int to_scene(const bsdfd_wf_scene* s, int row_begin, int row_end, int spp, Scene
 extern "C" {
 
 int bsdfd_wf_primary(const bsdfd_wf_scene* scene, int32_t row_begin, int32_t row_end, int32_t spp, uint64_t seed,
-                     uint64_t pass, float* wi, float* wl, float* nrm, float* dir, void* stream) {
+                     uint64_t pass, float* wi, float* wl, float* nrm, float* dir, int64_t* material, void* stream) {
     Scene sc;
     if (int rc = to_scene(scene, row_begin, row_end, spp, sc)) return rc;
     const long long n = (long long)(row_end - row_begin) * sc.width * spp;
@@ -225,14 +272,16 @@ int bsdfd_wf_primary(const bsdfd_wf_scene* scene, int32_t row_begin, int32_t row
     const long long blocks = (n + 255) / 256;
     if (blocks > 0x7fffffffLL) return bsdfd_fail_(BSDFD_EINVAL, "tile too large for one launch");
     hipLaunchKernelGGL(primary_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), sc,
-                       row_begin, row_end, spp, (unsigned long long)seed, (unsigned long long)pass, wi, wl, nrm, dir);
+                       row_begin, row_end, spp, (unsigned long long)seed, (unsigned long long)pass, wi, wl, nrm, dir,
+                       reinterpret_cast<long long*>(material));
     HIP_TRY(hipGetLastError());
     return BSDFD_OK;
 }
 
 int bsdfd_wf_shade(const bsdfd_wf_scene* scene, const float* env, int32_t row_begin, int32_t row_end, int32_t spp,
                    const float* wo, const float* pdf_o, const float* wl, const float* pdf_l, const float* nrm,
-                   const float* dir, const float* f_o, const float* f_l, float* film, void* stream) {
+                   const float* dir, const float* f_o, const float* f_l, const float* wi, const int64_t* material,
+                   float* film, void* stream) {
     Scene sc;
     if (int rc = to_scene(scene, row_begin, row_end, spp, sc)) return rc;
     if (sc.env_w <= 0 || sc.env_h <= 0) return bsdfd_fail_(BSDFD_EINVAL, "environment map size must be positive");
@@ -240,9 +289,12 @@ int bsdfd_wf_shade(const bsdfd_wf_scene* scene, const float* env, int32_t row_be
     if (npix == 0) return BSDFD_OK;
     if (!env || !wo || !pdf_o || !wl || !pdf_l || !nrm || !dir || !film)
         return bsdfd_fail_(BSDFD_EINVAL, "null pointer");
+    if (material && !wi) return bsdfd_fail_(BSDFD_EINVAL, "the material ids need the wi array (floor reflectance)");
+    if (sc.has_plane && !material) return bsdfd_fail_(BSDFD_EINVAL, "a scene with a floor needs the material ids");
     const long long blocks = (npix + 255) / 256;
     hipLaunchKernelGGL(shade_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), sc, env,
-                       row_begin, row_end, spp, wo, pdf_o, wl, pdf_l, nrm, dir, f_o, f_l, film);
+                       row_begin, row_end, spp, wo, pdf_o, wl, pdf_l, nrm, dir, f_o, f_l, wi,
+                       reinterpret_cast<const long long*>(material), film);
     HIP_TRY(hipGetLastError());
     return BSDFD_OK;
 }

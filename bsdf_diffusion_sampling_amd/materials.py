@@ -123,22 +123,24 @@ class MaterialTable:
         rc = rc or flush()
         _lib.check(rc)
 
-    def _buckets(self, material_id):
+    def _buckets(self, material_id, extra_bins: int = 0):
         if isinstance(material_id, tuple):  # a plan from bucket(): (perm, counts)
             return material_id
         if material_id.dtype != torch.int64:
             material_id = material_id.long()
-        perm, counts = bucket_by_material(material_id, len(self))
+        perm, counts = bucket_by_material(material_id, len(self) + extra_bins)
         counts = counts.cpu().tolist()
         if sum(counts) != material_id.shape[0]:
-            raise ValueError(f"material ids must be in [0, {len(self)})")
+            raise ValueError(f"material ids must be in [0, {len(self) + extra_bins})")
         return perm, counts
 
-    def bucket(self, material_id: torch.Tensor):
+    def bucket(self, material_id: torch.Tensor, extra_bins: int = 0):
         """Bucket a wavefront once and reuse the plan for its sample() and pdf() calls (a renderer asks both
         for the same intersections): pass the returned value in place of ``material_id``.  The stable sort
-        of 16 Mi ids costs 1.7 ms — 15 % of a sample() call."""
-        return self._buckets(material_id)
+        of 16 Mi ids costs 0.2 ms natively (1.7 ms with torch.argsort).  ``extra_bins``: ids len(self) ..
+        len(self)+extra_bins-1 are lanes that carry no material (a renderer's floor hits and misses); they
+        sort behind the materials, are not evaluated, and their outputs are zero."""
+        return self._buckets(material_id, extra_bins)
 
     def sample(self, material_id: torch.Tensor, wi: torch.Tensor, seed: int = 0, offset: int = 0,
                T: Optional[int] = None, x0: Optional[torch.Tensor] = None, segmented: bool = True):
@@ -178,20 +180,26 @@ class MaterialTable:
         """sample(wi) and pdf(wi, wl) for the same material-tagged intersections, one launch per kernel
         signature (``bsdfd_plugin_sample_pdf_multi``) -> (wo [N,3], pdf(wo) [N], pdf(wl) [N]) in the callers' order."""
         perm, counts = self._buckets(material_id)
-        wi_s, wl_s = wi[perm].contiguous(), wl[perm].contiguous()
-        x0_s = None if x0 is None else x0[perm].contiguous()
+        n_mat = sum(counts[: len(self)])            # lanes behind it (extra bins) carry no material
+        rows = perm[:n_mat]
+        wi_s, wl_s = wi[rows].contiguous(), wl[rows].contiguous()
+        x0_s = None if x0 is None else x0[rows].contiguous()
         wo_s = torch.empty_like(wi_s)
-        po_s = torch.empty(wi_s.shape[0], dtype=torch.float32, device=wi.device)
+        po_s = torch.empty(n_mat, dtype=torch.float32, device=wi.device)
         pl_s = torch.empty_like(po_s)
-        seg_end = list(__import__("itertools").accumulate(counts))
+        seg_end = list(__import__("itertools").accumulate(counts[: len(self)]))
         with torch.cuda.device(wi.device):
             for (dom, w, nh, prec, Tm, var), members in self._groups().items():
                 self._multi("sample_pdf", members, seg_end, Tm if T is None else T, var, wi_s, (x0_s, wl_s), seed,
                             offset, wo_s, (po_s, pl_s))
-        wo, po, pl = torch.empty_like(wo_s), torch.empty_like(po_s), torch.empty_like(pl_s)
-        wo[perm] = wo_s
-        po[perm] = po_s
-        pl[perm] = pl_s
+        full = n_mat == wi.shape[0]
+        mk = torch.empty if full else torch.zeros
+        wo = mk(wi.shape, dtype=torch.float32, device=wi.device)
+        po = mk(wi.shape[0], dtype=torch.float32, device=wi.device)
+        pl = mk(wi.shape[0], dtype=torch.float32, device=wi.device)
+        wo[rows] = wo_s
+        po[rows] = po_s
+        pl[rows] = pl_s
         return wo, po, pl
 
     def pdf(self, material_id: torch.Tensor, wi: torch.Tensor, wo: torch.Tensor, T: Optional[int] = None,

@@ -95,6 +95,7 @@ class WavefrontRenderer:
         self.use_ground_truth = has_gt if use_ground_truth is None else bool(use_ground_truth)
         if self.use_ground_truth and not has_gt:
             raise ValueError("use_ground_truth needs a plugin with a native MeasuredBSDF (props['measured_dir'])")
+        self.needs_material_ids = False
         self.camera = camera or Camera()
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         env = make_sky() if env is None else env
@@ -122,6 +123,8 @@ class WavefrontRenderer:
             b = dict(wi=mk(n, 3), wl=mk(n, 3), nrm=mk(n, 3), dir=mk(n, 3), wo=mk(n, 3), pdf_o=mk(n), pdf_l=mk(n))
             if self.use_ground_truth:
                 b.update(f_o=mk(n, 3), f_l=mk(n, 3))
+            if self.needs_material_ids:
+                b["mat"] = torch.empty((n,), dtype=torch.int64, device=self.device)
             self._buf = {n: b}  # one tile shape at a time
         return b
 
@@ -136,7 +139,8 @@ class WavefrontRenderer:
         p = lambda t: C.c_void_p(t.data_ptr())
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().bsdfd_wf_primary(C.byref(self.scene), row_begin, row_end, spp, seed, pass_idx,
-                                                   p(b["wi"]), p(b["wl"]), p(b["nrm"]), p(b["dir"]), self._stream()))
+                                                   p(b["wi"]), p(b["wl"]), p(b["nrm"]), p(b["dir"]),
+                                                   p(b["mat"]) if "mat" in b else None, self._stream()))
         return b
 
     def shade(self, row_begin: int, row_end: int, spp: int, b, film: torch.Tensor):
@@ -150,7 +154,8 @@ class WavefrontRenderer:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().bsdfd_wf_shade(C.byref(self.scene), p(self.env), row_begin, row_end, spp,
                                                  p(b["wo"]), p(b["pdf_o"]), p(b["wl"]), p(b["pdf_l"]), p(b["nrm"]),
-                                                 p(b["dir"]), f_o, f_l, p(film), self._stream()))
+                                                 p(b["dir"]), f_o, f_l, p(b["wi"]),
+                                                 p(b["mat"]) if "mat" in b else None, p(film), self._stream()))
 
     # -- one pass over a tile ------------------------------------------------------------------------
     def render_pass(self, film: torch.Tensor, row_begin: int, row_end: int, spp: int, seed: int, pass_idx: int,
@@ -196,3 +201,94 @@ class WavefrontRenderer:
         w = self.camera.width
         full = gather_to_root(tile.reshape(r1 - r0, w * 3), self.camera.height)
         return None if full is None else full.reshape(self.camera.height, w, 3)
+
+
+# ball layout of the reference's matpreview/disney_bsdf_array0_envmap.xml (12 `mybsdf` balls in three rows;
+# the scene is z-up with balls of radius ~0.5 translated by (x, y, z): here y-up, (x, y, z)_ref -> (x, z, -y))
+ARRAY0_LAYOUT = [(-4.0, 1.0, 0.0), (-3.0, 2.0, 0.0), (-2.0, 3.0, 0.0), (-1.0, 4.0, 0.0),
+                 (-3.5, 0.5, -0.75), (-2.5, 1.5, -0.75), (-1.5, 2.5, -0.75), (-0.5, 3.5, -0.75),
+                 (-2.0, -0.5, -0.9), (-1.15, 0.35, -0.9), (-0.3, 1.2, -0.9), (0.55, 2.05, -0.9)]
+ARRAY0_MATERIALS = ["aniso_brushed_aluminium_1_rgb", "aniso_copper_sheet_rgb", "aniso_green_pvc_rgb",
+                    "aniso_metallic_paper_copper_rgb", "aniso_metallic_paper_gold_rgb", "aniso_miro_7_rgb",
+                    "aniso_morpho_melenaus_rgb", "aniso_sari_silk_2color_rgb", "aurora_white_rgb",
+                    "cc_amber_citrine_rgb", "cc_blue_agat_rgb", "cc_green_malachite_rgb"]
+
+
+def array0_scene(width: int = 683, height: int = 512):
+    """Camera, ball centres and radii approximating matpreview/disney_bsdf_array0_envmap.xml (sensor :362-381:
+    origin (3.90, -3.46, 3.25) looking along (-0.65, 0.61, -0.44) in the z-up scene, fov 28.84 deg on the
+    smaller axis, 1366x1024 film).  There the balls are the matpreview shell meshes on three steps of
+    different height; here they are spheres of radius 0.33 resting on one floor, same (x, y) layout."""
+    radius = 0.33
+    centers = [(x, radius, -y) for x, y, _ in ARRAY0_LAYOUT]
+    fov_smaller = 28.8415
+    fov_x = 2 * math.degrees(math.atan(math.tan(math.radians(fov_smaller) / 2) * max(width / height, 1.0)))
+    cx = sum(c[0] for c in centers) / len(centers)
+    cz = sum(c[2] for c in centers) / len(centers)
+    cam = Camera(origin=(3.89558, 3.25463 + 1.6, 3.46243), target=(cx, radius, cz), up=(0.0, 1.0, 0.0),  # raised: all 12 visible
+                 fov_deg=fov_x, width=width, height=height)
+    return cam, centers, [radius] * len(centers)
+
+
+class ArrayRenderer(WavefrontRenderer):
+    """Several material balls, one material each (``materials.MaterialTable``), over a checkerboard floor —
+    the shape of the reference's matpreview array scenes (12 ``mybsdf`` instances per scene).  Per pass:
+    primary rays (with material ids) -> one stable bucketing of the wavefront (``bsdfd_bucket_by_material``;
+    floor hits and misses sort behind the materials) -> ONE fused sample+pdf launch per kernel signature
+    (``bsdfd_plugin_sample_pdf_multi``) -> shade.  ``ground_truth``: {material index: MeasuredBSDF} for the
+    balls that have an RGL tensor file; the others shade with the proxy ``f cos = albedo * pdf``.
+    The Philox counter of a path is its row in the bucketed order, so images of different row splits agree
+    statistically, not bit for bit (the single-ball renderer is split-invariant)."""
+
+    def __init__(self, table, centers, radii, camera: Optional[Camera] = None, env: Optional[torch.Tensor] = None,
+                 floor: bool = True, checker=(0.4, 0.2, 2.0), albedo=(1.0, 1.0, 1.0), ground_truth=None,
+                 device: Optional[torch.device] = None):
+        if len(centers) != len(table) or len(radii) != len(table):
+            raise ValueError("one ball per material of the table")
+        if not 1 <= len(table) <= 32:
+            raise ValueError("1..32 balls")
+
+        class _Tint:  # what WavefrontRenderer reads from a plugin
+            pass
+        tint = _Tint()
+        tint.albedo = torch.tensor(albedo, dtype=torch.float32)
+        tint.bsdf = None
+        super().__init__(tint, camera, env, sphere_center=centers[0], sphere_radius=radii[0], device=device,
+                         use_ground_truth=False)
+        self.table = table
+        self.ground_truth = dict(ground_truth or {})
+        self.use_ground_truth = bool(self.ground_truth)   # f arrays are then filled for every path
+        self.needs_material_ids = True
+        sc = self.scene
+        sc.n_extra_spheres = len(centers) - 1
+        for k in range(1, len(centers)):
+            sc.extra_spheres[k - 1] = (C.c_float * 4)(*[float(v) for v in centers[k]], float(radii[k]))
+        sc.has_plane = 1 if floor else 0
+        sc.plane_y = 0.0
+        sc.checker_color0, sc.checker_color1, sc.checker_scale = (float(v) for v in checker)
+
+    def render_pass(self, film: torch.Tensor, row_begin: int, row_end: int, spp: int, seed: int, pass_idx: int,
+                    x0: Optional[torch.Tensor] = None):
+        n = (row_end - row_begin) * self.camera.width * spp
+        if n == 0:
+            return
+        b = self.primary(row_begin, row_end, spp, seed, pass_idx)
+        plan = self.table.bucket(b["mat"], extra_bins=2)          # floor hits and misses behind the materials
+        offset = row_begin * self.camera.width * spp
+        skey = (seed * 0x9E3779B97F4A7C15 + pass_idx + 1) & 0xFFFFFFFFFFFFFFFF
+        b["wo"], b["pdf_o"], b["pdf_l"] = self.table.sample_pdf(plan, b["wi"], b["wl"], seed=skey, offset=offset)
+        if self.use_ground_truth:
+            alb = self.plugin.albedo.to(self.device)
+            b["f_o"] = b["pdf_o"][:, None] * alb                  # proxy f cos = albedo * pdf where no file exists
+            b["f_l"] = b["pdf_l"][:, None] * alb
+            perm, counts = plan
+            lo = 0
+            for m, c in enumerate(counts[: len(self.table)]):
+                if c and m in self.ground_truth:
+                    rows = perm[lo:lo + c]
+                    wi_m = b["wi"][rows].contiguous()
+                    b["f_o"][rows] = self.ground_truth[m].eval_t(wi_m, b["wo"][rows].contiguous(), tint=alb)
+                    b["f_l"][rows] = self.ground_truth[m].eval_t(wi_m, b["wl"][rows].contiguous(), tint=alb)
+                lo += c
+            b["f_o"], b["f_l"] = b["f_o"].contiguous(), b["f_l"].contiguous()
+        self.shade(row_begin, row_end, spp, b, film)

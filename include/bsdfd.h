@@ -219,21 +219,31 @@ typedef struct bsdfd_wf_scene {
     float sphere_radius;
     float albedo[3];                                               /* props["albedo"] of the plugin */
     int32_t env_width, env_height;                                 /* environment map [H,W,3] fp32 */
+    /* array scenes (matpreview/disney_bsdf_array*.xml: 12 balls with one `mybsdf` material each over a
+     * checkerboard floor): ball 0 is the sphere above, balls 1..n_extra_spheres follow; ball k carries
+     * material k.  All zero = the single-ball scene. */
+    int32_t n_extra_spheres;                                       /* 0..31 */
+    float extra_spheres[31][4];                                    /* centre xyz, radius */
+    int32_t has_plane;                                             /* diffuse checkerboard floor y = plane_y */
+    float plane_y, checker_scale, checker_color0, checker_color1;
 } bsdfd_wf_scene;
 
 /* Primary rays of rows [row_begin,row_end), spp jittered samples per pixel, pass index `pass`:
  * wi [N,3] local incoming direction ((0,0,1) for rays that miss the sphere), wl [N,3] cosine-weighted
- * light-sample direction (local), nrm [N,3] world normal (0 for a miss), dir [N,3] world ray direction. */
+ * light-sample direction (local), nrm [N,3] world normal (0 for a miss), dir [N,3] world ray direction,
+ * material [N] (or NULL): ball index = material index, n_balls for the floor (its reflectance is then
+ * in the wi slot), n_balls + 1 for a miss — the ids bsdfd_bucket_by_material sorts. */
 int bsdfd_wf_primary(const bsdfd_wf_scene* scene, int32_t row_begin, int32_t row_end, int32_t spp,
                      uint64_t seed, uint64_t pass, float* wi, float* wl, float* nrm, float* dir,
-                     void* hip_stream);
+                     int64_t* material, void* hip_stream);
 /* One-bounce MIS estimate: wo/pdf_o from plugin sample(), pdf_l = plugin pdf(wi, wl);
  * f_o / f_l [N,3] = plugin eval(wi, wo) / eval(wi, wl) (f cos, albedo included) or both NULL: then the
- * proxy f cos = albedo * pdf is used.  film [row_end-row_begin, width, 3] += mean over the spp samples. */
+ * proxy f cos = albedo * pdf is used.  wi / material: the arrays of bsdfd_wf_primary, needed (non-NULL)
+ * for scenes with a floor.  film [row_end-row_begin, width, 3] += mean over the spp samples. */
 int bsdfd_wf_shade(const bsdfd_wf_scene* scene, const float* env, int32_t row_begin, int32_t row_end,
                    int32_t spp, const float* wo, const float* pdf_o, const float* wl, const float* pdf_l,
-                   const float* nrm, const float* dir, const float* f_o, const float* f_l, float* film,
-                   void* hip_stream);
+                   const float* nrm, const float* dir, const float* f_o, const float* f_l, const float* wi,
+                   const int64_t* material, float* film, void* hip_stream);
 
 const char* bsdfd_last_error(void);
 const char* bsdfd_version(void);

@@ -58,9 +58,11 @@ def onb(n):
     return s.astype(F), t.astype(F)
 
 
-def primary(scene: dict, row_begin: int, row_end: int, spp: int, seed: int, pass_idx: int):
-    """scene: dict(origin, right, up, forward, tan_half_fov, width, height, center, radius).
-    -> wi, wl, nrm, dir, each [N,3] fp32 (path order: row, col, sample)."""
+def primary(scene: dict, row_begin: int, row_end: int, spp: int, seed: int, pass_idx: int, with_material=False):
+    """scene: dict(origin, right, up, forward, tan_half_fov, width, height, center, radius [, spheres =
+    [(centre, radius), ...] replacing center/radius, plane = dict(y, c0, c1, scale)]).
+    -> wi, wl, nrm, dir, each [N,3] fp32 (path order: row, col, sample) [, material ids [N] int64:
+    ball index, n_balls for the floor (its reflectance in the wi slot), n_balls + 1 for a miss]."""
     w, h = scene["width"], scene["height"]
     rows = np.arange(row_begin, row_end, dtype=np.int64)
     row = np.repeat(rows, w * spp)
@@ -75,27 +77,57 @@ def primary(scene: dict, row_begin: int, row_end: int, spp: int, seed: int, pass
     thf = F(scene["tan_half_fov"])
     sx = (F(2.0) * fx - F(1.0)) * thf
     sy = (F(1.0) - F(2.0) * fy) * thf * (F(h) / F(w))
-    right, up, fwd, o, c = (np.asarray(scene[k], dtype=F) for k in ("right", "up", "forward", "origin", "center"))
+    right, up, fwd, o = (np.asarray(scene[k], dtype=F) for k in ("right", "up", "forward", "origin"))
     d = fwd[None, :] + sx[:, None] * right[None, :] + sy[:, None] * up[None, :]
     d = (d / np.sqrt((d * d).sum(1, keepdims=True))).astype(F)
-    oc = (o - c).astype(F)
-    radius = F(scene["radius"])
-    b = (d * oc[None, :]).sum(1)
-    perp = oc[None, :] - b[:, None] * d
-    disc = radius * radius - (perp * perp).sum(1)
-    t = -b - np.sqrt(np.maximum(disc, F(0.0)))
-    hit = (disc > 0) & (t > 0)
-    nn = (oc[None, :] + t[:, None] * d) / radius
+    spheres = scene.get("spheres") or [(scene["center"], scene["radius"])]
+    n = len(d)
+    t_best = np.full(n, F(3.0e38), dtype=F)
+    hit_k = np.full(n, -1, dtype=np.int64)
+    for k, (ck, rk) in enumerate(spheres):
+        oc = (o - np.asarray(ck, dtype=F)).astype(F)
+        radius = F(rk)
+        b = (d * oc[None, :]).sum(1)
+        perp = oc[None, :] - b[:, None] * d
+        disc = radius * radius - (perp * perp).sum(1)
+        t = -b - np.sqrt(np.maximum(disc, F(0.0)))
+        better = (disc > 0) & (t > 0) & (t < t_best)
+        t_best = np.where(better, t, t_best).astype(F)
+        hit_k = np.where(better, k, hit_k)
+    plane_hit = np.zeros(n, dtype=bool)
+    plane = scene.get("plane")
+    if plane is not None:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tp = ((F(plane["y"]) - o[1]) / d[:, 1]).astype(F)
+        plane_hit = (d[:, 1] < 0) & (tp > 0) & (tp < t_best)
+        t_best = np.where(plane_hit, tp, t_best).astype(F)
+        hit_k = np.where(plane_hit, -1, hit_k)
+    hit = hit_k >= 0
+    cs = np.asarray([np.asarray(ck, dtype=F) for ck, _ in spheres], dtype=F)[np.maximum(hit_k, 0)]
+    rs = np.asarray([F(rk) for _, rk in spheres], dtype=F)[np.maximum(hit_k, 0)]
+    occ = (o[None, :] - cs).astype(F)
+    nn = (occ + t_best[:, None] * d) / rs[:, None]
     nn = (nn / np.sqrt((nn * nn).sum(1, keepdims=True))).astype(F)
     nn = np.where(hit[:, None], nn, F(0.0)).astype(F)
     safe_n = np.where(hit[:, None], nn, np.array([0, 0, 1], dtype=F))
     fs, ft = onb(safe_n)
     wi = np.stack([-(d * fs).sum(1), -(d * ft).sum(1), -(d * safe_n).sum(1)], 1)
     wi = np.where(hit[:, None], wi, np.array([0, 0, 1], dtype=F)).astype(F)
+    material = np.where(hit, hit_k, len(spheres) + 1)
+    if plane is not None:
+        h = o[None, :] + t_best[:, None] * d
+        cx = np.floor(h[:, 0] * F(plane["scale"])).astype(np.int64)
+        cz = np.floor(h[:, 2] * F(plane["scale"])).astype(np.int64)
+        refl = np.where(((cx + cz) & 1) == 1, F(plane["c1"]), F(plane["c0"])).astype(F)
+        nn = np.where(plane_hit[:, None], np.array([0, 1, 0], dtype=F), nn).astype(F)
+        wi = np.where(plane_hit[:, None], refl[:, None], wi).astype(F)
+        material = np.where(plane_hit, len(spheres), material)
     u2, u3 = _u01_open(u[2]), _u01_half_open(u[3])
     r = np.sqrt(u2)
     ang = F(6.28318530717958647692) * u3
     wl = np.stack([r * np.cos(ang), r * np.sin(ang), np.sqrt(np.maximum(F(1.0) - u2, F(0.0)))], 1).astype(F)
+    if with_material:
+        return wi, wl, nrm_f32(nn), d, material.astype(np.int64)
     return wi, wl, nrm_f32(nn), d
 
 
@@ -130,7 +162,7 @@ def mis_power(pa, pb):
     return np.where(pa > 0, w, 0.0)
 
 
-def shade(scene: dict, env, spp: int, wo, pdf_o, wl, pdf_l, nrm, dir_, f_o=None, f_l=None):
+def shade(scene: dict, env, spp: int, wo, pdf_o, wl, pdf_l, nrm, dir_, f_o=None, f_l=None, wi=None, material=None):
     """-> per-pixel mean over spp of the one-bounce MIS estimate, [npix, 3] (fp64 accumulation).
     f_o / f_l: ground-truth f cos (albedo included) at (wi, wo) / (wi, wl); None -> proxy f cos = albedo pdf."""
     env = env.astype(np.float64)
@@ -156,4 +188,8 @@ def shade(scene: dict, env, spp: int, wo, pdf_o, wl, pdf_l, nrm, dir_, f_o=None,
     Ll = wl_w[:, None] * weight_l * env_lookup(env, to_world(wl.astype(np.float64)).astype(F))
     L = Lb + Ll
     L = np.where(miss[:, None], env_lookup(env, dir_), L)
+    if material is not None:  # diffuse floor, cosine-sampled: reflectance (in the wi slot) x radiance
+        n_balls = len(scene.get("spheres") or [0])
+        floor = material == n_balls
+        L = np.where(floor[:, None], wi[:, 0:1].astype(np.float64) * env_lookup(env, to_world(wl.astype(np.float64)).astype(F)), L)
     return L.reshape(-1, spp, 3).mean(1)

@@ -135,3 +135,40 @@ def test_png_writer_roundtrip(tmp_path):
     rows = zlib.decompress(chunks[b"IDAT"])
     back = np.frombuffer(rows, dtype=np.uint8).reshape(5, 1 + 7 * 3)[:, 1:].reshape(5, 7, 3)
     assert np.array_equal(back, rgb8)
+
+
+def test_array_scene_oracle_geometry():
+    """Ball arrays over a checkerboard floor (the shape of matpreview/disney_bsdf_array*.xml)."""
+    from bsdf_diffusion_sampling_amd.wavefront import ARRAY0_LAYOUT, ARRAY0_MATERIALS, array0_scene
+    import math
+    cam, centers, radii = array0_scene(96, 72)
+    assert len(centers) == len(ARRAY0_LAYOUT) == len(ARRAY0_MATERIALS) == 12
+    r, u, f = cam.basis()
+    sc = dict(origin=cam.origin, right=r, up=u, forward=f, tan_half_fov=math.tan(math.radians(cam.fov_deg) / 2),
+              width=cam.width, height=cam.height, spheres=list(zip(centers, radii)),
+              plane=dict(y=0.0, c0=0.4, c1=0.2, scale=2.0), albedo=(1.0, 1.0, 1.0))
+    wi, wl, nrm, d, mat = WO.primary(sc, 0, cam.height, 1, seed=1, pass_idx=0, with_material=True)
+    n_b = len(centers)
+    assert set(np.unique(mat)) <= set(range(n_b + 2))
+    assert len(np.unique(mat[mat < n_b])) == 12          # the camera sees all balls
+    floor, miss, ball = mat == n_b, mat == n_b + 1, mat < n_b
+    assert floor.mean() > 0.2 and ball.mean() > 0.1 and floor.sum() + miss.sum() + ball.sum() == len(mat)
+    sc_up = dict(sc, forward=np.array([0.0, 1.0, 0.0]), right=np.array([1.0, 0.0, 0.0]), up=np.array([0.0, 0.0, 1.0]))
+    assert (WO.primary(sc_up, 0, 4, 1, 1, 0, with_material=True)[4] == n_b + 1).all()      # looking up: only sky
+    assert (nrm[floor] == [0, 1, 0]).all() and (nrm[miss] == 0).all()
+    assert set(np.unique(wi[floor])) == {np.float32(0.4), np.float32(0.2)}      # the two checker reflectances
+    assert np.allclose((nrm[ball] ** 2).sum(1), 1, atol=1e-5) and (wi[ball, 2] > 0).all()
+    # the hit point of a ball path lies on that ball
+    o = np.asarray(cam.origin)
+    for k in range(n_b):
+        sel = mat == k
+        if sel.any():
+            p = np.asarray(centers[k]) + radii[k] * nrm[sel].astype(np.float64)
+            dirs = (p - o) / np.linalg.norm(p - o, axis=1, keepdims=True)
+            assert np.abs(dirs - d[sel]).max() < 1e-4
+    # shading: constant environment E -> floor pixels are reflectance * E, misses E
+    env = np.full((4, 8, 3), 1.5, dtype=np.float32)
+    z = np.zeros_like(wl)
+    img = WO.shade(sc, env, 1, z, np.zeros(len(wl), np.float32), wl, np.zeros(len(wl), np.float32), nrm, d,
+                   wi=wi, material=mat)
+    assert np.allclose(img[floor], 1.5 * wi[floor, :1], rtol=1e-5) and np.allclose(img[miss], 1.5, rtol=1e-5)
