@@ -106,7 +106,7 @@ def primary(scene: dict, row_begin: int, row_end: int, spp: int, seed: int, pass
     cs = np.asarray([np.asarray(ck, dtype=F) for ck, _ in spheres], dtype=F)[np.maximum(hit_k, 0)]
     rs = np.asarray([F(rk) for _, rk in spheres], dtype=F)[np.maximum(hit_k, 0)]
     occ = (o[None, :] - cs).astype(F)
-    nn = (occ + t_best[:, None] * d) / rs[:, None]
+    nn = (occ + np.where(hit, t_best, F(0.0))[:, None] * d) / rs[:, None]   # (misses: any finite vector, masked below)
     nn = (nn / np.sqrt((nn * nn).sum(1, keepdims=True))).astype(F)
     nn = np.where(hit[:, None], nn, F(0.0)).astype(F)
     safe_n = np.where(hit[:, None], nn, np.array([0, 0, 1], dtype=F))
@@ -115,7 +115,7 @@ def primary(scene: dict, row_begin: int, row_end: int, spp: int, seed: int, pass
     wi = np.where(hit[:, None], wi, np.array([0, 0, 1], dtype=F)).astype(F)
     material = np.where(hit, hit_k, len(spheres) + 1)
     if plane is not None:
-        h = o[None, :] + t_best[:, None] * d
+        h = o[None, :] + np.where(plane_hit, t_best, F(0.0))[:, None] * d
         cx = np.floor(h[:, 0] * F(plane["scale"])).astype(np.int64)
         cz = np.floor(h[:, 2] * F(plane["scale"])).astype(np.int64)
         refl = np.where(((cx + cz) & 1) == 1, F(plane["c1"]), F(plane["c0"])).astype(F)
