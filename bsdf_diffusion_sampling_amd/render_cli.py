@@ -43,6 +43,9 @@ def tonemap(img: np.ndarray) -> np.ndarray:
 def main(plugin_cls, default_out: str) -> None:
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--filename", default="aniso_miro_7_rgb", help="material (the reference's props['filename'])")
+    ap.add_argument("--scene_file", default=None,
+                    help="a reference scene (rendering/matpreview/disney_bsdf_array*.xml, the reference CLI's "
+                         "--scene_file): its `mybsdf` materials and ball positions are rendered as an array scene")
     ap.add_argument("--measured_dir", default=None, help="directory with <filename>.bsdf: render with the ground-truth f")
     ap.add_argument("--spp", type=int, default=4, help="samples per pixel per pass (the reference: SPP = 4)")
     ap.add_argument("--passes", type=int, default=128, help="number of passes (the reference: 128)")
@@ -59,10 +62,23 @@ def main(plugin_cls, default_out: str) -> None:
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
         dist.init_process_group(os.environ.get("BSDFD_BENCH_BACKEND", "nccl"))
     from . import wavefront as WF
-    props = {"filename": a.filename, "albedo": a.albedo}
-    if a.measured_dir:
-        props["measured_dir"] = a.measured_dir
-    r = WF.WavefrontRenderer(plugin_cls(props), WF.Camera(width=a.size, height=a.size))
+    if a.scene_file:
+        from .materials import MaterialTable
+        from .measured import MeasuredBSDF, find_measured_file
+        names, cam, centers, radii = WF.scene_from_matpreview_xml(a.scene_file, a.size * 4 // 3, a.size)
+        tab = MaterialTable([n + "_" + plugin_cls.DOMAIN_NAME for n in names])
+        gts = {}
+        if a.measured_dir:
+            for i, n in enumerate(names):
+                f = find_measured_file(n, a.measured_dir)
+                if f:
+                    gts[i] = MeasuredBSDF(f)
+        r = WF.ArrayRenderer(tab, centers, radii, camera=cam, albedo=a.albedo, ground_truth=gts)
+    else:
+        props = {"filename": a.filename, "albedo": a.albedo}
+        if a.measured_dir:
+            props["measured_dir"] = a.measured_dir
+        r = WF.WavefrontRenderer(plugin_cls(props), WF.Camera(width=a.size, height=a.size))
     t0 = time.time()
     img = r.render_sharded(a.passes, a.spp, seed=a.seed)
     torch.cuda.synchronize()
@@ -71,7 +87,9 @@ def main(plugin_cls, default_out: str) -> None:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         np.save(a.out + ".npy", img)
         write_png(a.out + ".png", tonemap(img))
-        print(f"Render time: {time.time() - t0:.3f} seconds ({a.size}x{a.size}, {a.passes} x {a.spp} spp, "
-              f"{'ground-truth f' if r.use_ground_truth else 'proxy f = albedo * pdf'}, {world} GPU(s)) -> {a.out}.png/.npy")
+        gt = (f"ground-truth f for {len(r.ground_truth)} of {len(r.table)} materials" if a.scene_file and r.use_ground_truth
+              else "ground-truth f" if r.use_ground_truth else "proxy f = albedo * pdf")
+        print(f"Render time: {time.time() - t0:.3f} seconds ({img.shape[1]}x{img.shape[0]}, {a.passes} x {a.spp} spp, "
+              f"{gt}, {world} GPU(s)) -> {a.out}.png/.npy")
     if world > 1:
         dist.destroy_process_group()

@@ -230,6 +230,46 @@ def array0_scene(width: int = 683, height: int = 512):
     return cam, centers, [radius] * len(centers)
 
 
+def parse_matpreview_xml(path: str):
+    """Materials and ball positions of a reference scene file (rendering/matpreview/disney_bsdf_array*.xml):
+    every <shape> that carries a <bsdf type="mybsdf"> contributes (props, (x, y, z)) — the string / integer
+    properties of the bsdf (``filename`` or ``idx``) and the last <translate> of its toWorld transform that
+    moves it in the ground plane.  Everything else in the file (meshes, integrator, emitter) belongs to Mitsuba."""
+    import xml.etree.ElementTree as ET
+    out = []
+    for shape in ET.parse(path).getroot().iter("shape"):
+        bsdf = next((b for b in shape.findall("bsdf") if b.get("type") == "mybsdf"), None)
+        if bsdf is None:
+            continue
+        props = {}
+        for child in bsdf:
+            if child.tag in ("string", "integer", "float") and child.get("name") is not None:
+                v = child.get("value")
+                props[child.get("name")] = int(v) if child.tag == "integer" else float(v) if child.tag == "float" else v
+        pos = (0.0, 0.0, 0.0)
+        for tr in shape.iter("translate"):
+            if tr.get("x") is not None or tr.get("y") is not None:
+                pos = tuple(float(tr.get(a, 0.0)) for a in ("x", "y", "z"))
+        out.append((props, pos))
+    return out
+
+
+def scene_from_matpreview_xml(path: str, width: int = 683, height: int = 512):
+    """(material names, camera, centres, radii) for ``ArrayRenderer`` from a reference scene file; ball layout and
+    camera direction as ``array0_scene`` (spheres of radius 0.33 on one floor, same ground-plane positions)."""
+    entries = parse_matpreview_xml(path)
+    if not entries:
+        raise ValueError(f"{path}: no <bsdf type='mybsdf'> shapes")
+    names = [str(p["filename"]) if "filename" in p else f"bsdf_{int(p['idx'])}" for p, _ in entries]
+    radius = 0.33
+    centers = [(x, radius, -y) for _, (x, y, _z) in entries]
+    cam0, _, _ = array0_scene(width, height)
+    cx = sum(c[0] for c in centers) / len(centers)
+    cz = sum(c[2] for c in centers) / len(centers)
+    cam = Camera(origin=cam0.origin, target=(cx, radius, cz), up=cam0.up, fov_deg=cam0.fov_deg, width=width, height=height)
+    return names, cam, centers, [radius] * len(centers)
+
+
 class ArrayRenderer(WavefrontRenderer):
     """Several material balls, one material each (``materials.MaterialTable``), over a checkerboard floor —
     the shape of the reference's matpreview array scenes (12 ``mybsdf`` instances per scene).  Per pass:

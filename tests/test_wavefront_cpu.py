@@ -172,3 +172,34 @@ def test_array_scene_oracle_geometry():
     img = WO.shade(sc, env, 1, z, np.zeros(len(wl), np.float32), wl, np.zeros(len(wl), np.float32), nrm, d,
                    wi=wi, material=mat)
     assert np.allclose(img[floor], 1.5 * wi[floor, :1], rtol=1e-5) and np.allclose(img[miss], 1.5, rtol=1e-5)
+
+
+def test_parse_reference_scene_file(tmp_path):
+    """The scene-file reader takes the `mybsdf` shapes of a reference-format Mitsuba XML (layout of
+    rendering/matpreview/disney_bsdf_array*.xml) and nothing else."""
+    from bsdf_diffusion_sampling_amd.wavefront import parse_matpreview_xml, scene_from_matpreview_xml
+    xml = """<?xml version="1.0" encoding="utf-8"?>
+<scene version="0.5.0">
+  <bsdf type="diffuse" id="__diffmat"><rgb name="reflectance" value="0.18 0.18 0.18"/></bsdf>
+  <shape type="serialized" id="Shell0">
+    <transform name="toWorld"><scale x="0.5" y="0.5" z="0.5"/><translate z="0.01"/><translate x="-4" y="1"/></transform>
+    <bsdf type="mybsdf"><string name='filename' value='chm_orange_rgb'/></bsdf>
+  </shape>
+  <shape type="serialized" id="Interior0">
+    <transform name="toWorld"><translate x="-4" y="1"/></transform><ref name="bsdf" id="__diffmat"/>
+  </shape>
+  <shape type="serialized" id="Shell1">
+    <transform name="toWorld"><translate z="0.01"/><translate x="-2.5" y="1.5" z="-0.75"/></transform>
+    <bsdf type="mybsdf"><integer name='idx' value='21'/><integer name='type' value='1'/></bsdf>
+  </shape>
+</scene>"""
+    p = tmp_path / "scene.xml"
+    p.write_text(xml)
+    e = parse_matpreview_xml(str(p))
+    assert e == [({"filename": "chm_orange_rgb"}, (-4.0, 1.0, 0.0)), ({"idx": 21, "type": 1}, (-2.5, 1.5, -0.75))]
+    names, cam, centers, radii = scene_from_matpreview_xml(str(p), 64, 48)
+    assert names == ["chm_orange_rgb", "bsdf_21"] and radii == [0.33, 0.33]
+    assert centers == [(-4.0, 0.33, -1.0), (-2.5, 0.33, -1.5)] and (cam.width, cam.height) == (64, 48)
+    (tmp_path / "empty.xml").write_text("<scene version='0.5.0'></scene>")
+    with pytest.raises(ValueError, match="no <bsdf"):
+        scene_from_matpreview_xml(str(tmp_path / "empty.xml"))
