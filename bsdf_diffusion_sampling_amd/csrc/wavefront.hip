@@ -197,6 +197,10 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, const float* __res
             // BSDF-sampled direction: weight f cos / pdf.  With the ground truth (f_o = plugin eval(), which
             // already carries the albedo tint) that is f_o / pdf; without it the proxy f cos = albedo * pdf
             // (the nets model pdf ∝ lum(f cos)) gives weight = albedo.
+            // per-path opt-out: a NaN in the f arrays selects the proxy for that path (array scenes mix materials
+            // with and without a ground-truth file)
+            const bool gt_o = f_o && f_o[3 * p] == f_o[3 * p];
+            const bool gt_l = f_l && f_l[3 * p] == f_l[3 * p];
             const V3 o = ld3(wo + 3 * p);
             float pb = pdf_o[p];
             if (!(pb > 0.0f) || !isfinite(pb)) pb = 0.0f;
@@ -205,19 +209,19 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, const float* __res
                 float e[3];
                 env_lookup(env, sc.env_w, sc.env_h, o.x * fs + o.y * ft + o.z * n, e);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) L[c] += w * e[c] * (f_o ? f_o[3 * p + c] / pb : sc.albedo[c]);
+                for (int c = 0; c < 3; ++c) L[c] += w * e[c] * (gt_o ? f_o[3 * p + c] / pb : sc.albedo[c]);
             }
             // light-sampled direction (cosine hemisphere, pdf cos/pi): f cos / pdf_light
             const V3 l = ld3(wl + 3 * p);
             const float pl = l.z * inv_pi;
             float pbl = pdf_l[p];
             if (!(pbl > 0.0f) || !isfinite(pbl)) pbl = 0.0f;
-            if (pl > 0.0f && (pbl > 0.0f || f_l)) {
+            if (pl > 0.0f && (pbl > 0.0f || gt_l)) {
                 const float w = mis_power(pl, pbl) / pl;
                 float e[3];
                 env_lookup(env, sc.env_w, sc.env_h, l.x * fs + l.y * ft + l.z * n, e);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) L[c] += w * e[c] * (f_l ? f_l[3 * p + c] : sc.albedo[c] * pbl);
+                for (int c = 0; c < 3; ++c) L[c] += w * e[c] * (gt_l ? f_l[3 * p + c] : sc.albedo[c] * pbl);
             }
         }
 #pragma unroll

@@ -176,7 +176,7 @@ class MaterialTable:
         return wo, pdf
 
     def sample_pdf(self, material_id, wi: torch.Tensor, wl: torch.Tensor, seed: int = 0, offset: int = 0,
-                   T: Optional[int] = None, x0: Optional[torch.Tensor] = None):
+                   T: Optional[int] = None, x0: Optional[torch.Tensor] = None, return_bucketed: bool = False):
         """sample(wi) and pdf(wi, wl) for the same material-tagged intersections, one launch per kernel
         signature (``bsdfd_plugin_sample_pdf_multi``) -> (wo [N,3], pdf(wo) [N], pdf(wl) [N]) in the callers' order."""
         perm, counts = self._buckets(material_id)
@@ -200,6 +200,8 @@ class MaterialTable:
         wo[rows] = wo_s
         po[rows] = po_s
         pl[rows] = pl_s
+        if return_bucketed:  # the bucket-ordered arrays too (material m = rows seg_end[m-1] .. seg_end[m]) and `rows`
+            return wo, po, pl, dict(wi=wi_s, wl=wl_s, wo=wo_s, pdf_o=po_s, pdf_l=pl_s, rows=rows, seg_end=seg_end)
         return wo, po, pl
 
     def pdf(self, material_id: torch.Tensor, wi: torch.Tensor, wo: torch.Tensor, T: Optional[int] = None,

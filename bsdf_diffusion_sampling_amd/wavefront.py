@@ -316,19 +316,25 @@ class ArrayRenderer(WavefrontRenderer):
         plan = self.table.bucket(b["mat"], extra_bins=2)          # floor hits and misses behind the materials
         offset = row_begin * self.camera.width * spp
         skey = (seed * 0x9E3779B97F4A7C15 + pass_idx + 1) & 0xFFFFFFFFFFFFFFFF
-        b["wo"], b["pdf_o"], b["pdf_l"] = self.table.sample_pdf(plan, b["wi"], b["wl"], seed=skey, offset=offset)
-        if self.use_ground_truth:
-            alb = self.plugin.albedo.to(self.device)
-            b["f_o"] = b["pdf_o"][:, None] * alb                  # proxy f cos = albedo * pdf where no file exists
-            b["f_l"] = b["pdf_l"][:, None] * alb
-            perm, counts = plan
+        if not self.use_ground_truth:
+            b["wo"], b["pdf_o"], b["pdf_l"] = self.table.sample_pdf(plan, b["wi"], b["wl"], seed=skey, offset=offset)
+        else:
+            # ground truth where a tensor file exists, evaluated on the bucket-ordered arrays (a material's rows
+            # are contiguous there); NaN = "no ground truth for this path" -> the shade kernel uses the proxy
+            b["wo"], b["pdf_o"], b["pdf_l"], s = self.table.sample_pdf(plan, b["wi"], b["wl"], seed=skey,
+                                                                       offset=offset, return_bucketed=True)
+            alb = self.plugin.albedo
+            n_mat = s["wi"].shape[0]
+            fo_s = torch.full((n_mat, 3), float("nan"), dtype=torch.float32, device=self.device)
+            fl_s = torch.full((n_mat, 3), float("nan"), dtype=torch.float32, device=self.device)
             lo = 0
-            for m, c in enumerate(counts[: len(self.table)]):
-                if c and m in self.ground_truth:
-                    rows = perm[lo:lo + c]
-                    wi_m = b["wi"][rows].contiguous()
-                    b["f_o"][rows] = self.ground_truth[m].eval_t(wi_m, b["wo"][rows].contiguous(), tint=alb)
-                    b["f_l"][rows] = self.ground_truth[m].eval_t(wi_m, b["wl"][rows].contiguous(), tint=alb)
-                lo += c
-            b["f_o"], b["f_l"] = b["f_o"].contiguous(), b["f_l"].contiguous()
+            for m, hi in enumerate(s["seg_end"]):
+                if hi > lo and m in self.ground_truth:
+                    self.ground_truth[m].eval_t(s["wi"][lo:hi], s["wo"][lo:hi], out=fo_s[lo:hi], tint=alb)
+                    self.ground_truth[m].eval_t(s["wi"][lo:hi], s["wl"][lo:hi], out=fl_s[lo:hi], tint=alb)
+                lo = hi
+            b["f_o"].fill_(float("nan"))
+            b["f_l"].fill_(float("nan"))
+            b["f_o"][s["rows"]] = fo_s
+            b["f_l"][s["rows"]] = fl_s
         self.shade(row_begin, row_end, spp, b, film)

@@ -238,7 +238,7 @@ int bsdfd_wf_primary(const bsdfd_wf_scene* scene, int32_t row_begin, int32_t row
                      int64_t* material, void* hip_stream);
 /* One-bounce MIS estimate: wo/pdf_o from plugin sample(), pdf_l = plugin pdf(wi, wl);
  * f_o / f_l [N,3] = plugin eval(wi, wo) / eval(wi, wl) (f cos, albedo included) or both NULL: then the
- * proxy f cos = albedo * pdf is used.  wi / material: the arrays of bsdfd_wf_primary, needed (non-NULL)
+ * proxy f cos = albedo * pdf is used; a NaN in a path's f_o / f_l entry selects the proxy for that path.  wi / material: the arrays of bsdfd_wf_primary, needed (non-NULL)
  * for scenes with a floor.  film [row_end-row_begin, width, 3] += mean over the spp samples. */
 int bsdfd_wf_shade(const bsdfd_wf_scene* scene, const float* env, int32_t row_begin, int32_t row_end,
                    int32_t spp, const float* wo, const float* pdf_o, const float* wl, const float* pdf_l,

@@ -178,13 +178,16 @@ def shade(scene: dict, env, spp: int, wo, pdf_o, wl, pdf_l, nrm, dir_, f_o=None,
     albedo = np.asarray(scene["albedo"], dtype=np.float64)[None, :]
     with np.errstate(divide="ignore", invalid="ignore"):
         weight_b = albedo if f_o is None else np.where(pb[:, None] > 0, f_o.astype(np.float64) / pb[:, None], 0.0)
+    if f_o is not None:   # a NaN entry = no ground truth for that path: proxy
+        weight_b = np.where(np.isnan(f_o[:, :1]), albedo, weight_b)
     Lb = wb[:, None] * weight_b * env_lookup(env, to_world(wo.astype(np.float64)).astype(F))
     pl = wl[:, 2].astype(np.float64) * inv_pi
     pbl = np.where(np.isfinite(pdf_l) & (pdf_l > 0), pdf_l, 0.0).astype(np.float64)
-    ok = (pl > 0) & ((pbl > 0) | (f_l is not None))
+    gt_l = np.zeros(len(pl), dtype=bool) if f_l is None else ~np.isnan(f_l[:, 0])
+    ok = (pl > 0) & ((pbl > 0) | gt_l)
     with np.errstate(divide="ignore", invalid="ignore"):
         wl_w = np.where(ok, mis_power(pl, pbl) / pl, 0.0)
-    weight_l = albedo * pbl[:, None] if f_l is None else f_l.astype(np.float64)
+    weight_l = albedo * pbl[:, None] if f_l is None else np.where(gt_l[:, None], np.nan_to_num(f_l.astype(np.float64)), albedo * pbl[:, None])
     Ll = wl_w[:, None] * weight_l * env_lookup(env, to_world(wl.astype(np.float64)).astype(F))
     L = Lb + Ll
     L = np.where(miss[:, None], env_lookup(env, dir_), L)

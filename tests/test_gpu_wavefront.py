@@ -249,8 +249,9 @@ def test_array_scene_matches_oracle(gt):
     if gt:  # ball 0 (chm_orange) is shaded with its measured f, the others with the proxy
         rows = b["mat"] == 0
         assert rows.sum() > 50
-        pr = b["pdf_o"][rows][:, None] * np.ones(3)
-        assert np.abs(b["f_o"][rows] - pr).max() > 1e-3 and np.allclose(b["f_o"][b["mat"] == 1], b["pdf_o"][b["mat"] == 1][:, None])
+        assert np.isfinite(b["f_o"][rows]).all() and np.isfinite(b["f_l"][rows]).all()
+        assert np.abs(b["f_o"][rows] - b["pdf_o"][rows][:, None]).max() > 1e-3        # the measured f, not the proxy
+        assert np.isnan(b["f_o"][b["mat"] != 0]).all() and np.isnan(b["f_l"][b["mat"] != 0]).all()
 
 
 def test_array_scene_renders_and_shards():
