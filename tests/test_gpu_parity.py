@@ -391,7 +391,8 @@ def test_extreme_inputs_do_not_crash_and_fail_loudly():
     assert np.all(~np.isfinite(pb) | (pb == 0))
 
 
-@pytest.mark.parametrize("stem,variant", [("chm_orange_rgb_disk", 0), ("aniso_miro_7_rgb_spherical", 0), ("bsdf_3_spherical", 1)])
+@pytest.mark.parametrize("stem,variant", [("chm_orange_rgb_disk", 0), ("aniso_miro_7_rgb_spherical", 0), ("bsdf_3_spherical", 1),
+                                          ("aniso_miro_7_rgb_spherical_complex", 0)])
 def test_fused_sample_pdf_equals_the_two_calls(stem, variant):
     """bsdfd_plugin_sample_pdf = plugin_sample(wi) + plugin_pdf(wi, wl) on one evaluation of the prologue."""
     g, fw = load_case(stem)
