@@ -93,3 +93,32 @@ def test_calls_are_hip_graph_capturable():
     s.plugin_pdf(wi, wo, T=4, out=pdf_s)  # eager pdf of the replayed directions
     torch.cuda.synchronize()
     assert torch.equal(pdf_s, pdf_p)
+
+
+def test_create_destroy_does_not_leak_device_memory():
+    """Handles own their packed weights / tables (hipMalloc) and a ring of HIP events: 300 create-use-destroy
+    cycles must give the memory back."""
+    import ctypes as C
+    import gc
+    from conftest import load_case
+    from bsdf_diffusion_sampling_amd import _lib
+    from bsdf_diffusion_sampling_amd.measured import MeasuredBSDF
+    from bsdf_diffusion_sampling_amd.sampler import FlowSampler
+    g, fw = load_case("aniso_miro_7_rgb_spherical_complex")       # the largest weight image (~90 KB)
+    dev = torch.device("cuda", 0)
+    wi = torch.from_numpy(g["wi"][:256].astype(np.float32)).to(dev)
+    fixture = os.path.join(ROOT, "tests", "golden", "chm_orange_rgb.bsdf")
+
+    def cycle(n):
+        for _ in range(n):
+            s = FlowSampler(fw)
+            s.network_sampling(wi, None, T=2)
+            m = MeasuredBSDF(fixture)                                  # ~1.3 MB of tables
+            del s, m
+        gc.collect()
+        torch.cuda.synchronize()
+    cycle(20)
+    free0, _ = torch.cuda.mem_get_info()
+    cycle(300)
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, (free0, free1)                     # 300 leaked table sets would be ~400 MB
