@@ -195,6 +195,10 @@ int bsdfd_bucket_by_material(const int64_t* material_id, int64_t n, int32_t n_ma
     const size_t lds_count = (size_t)BK_CHUNK + (size_t)n_materials * BK_CNT_STRIDE;
     const size_t lds_scatter = (size_t)BK_CHUNK + (size_t)n_materials * (BK_CNT_STRIDE + 2 * BK_BASE_STRIDE) + (size_t)BK_CHUNK * 3 +
                                BK_MAX_MATERIALS * sizeof(long long) + (BK_MAX_MATERIALS + 1) * sizeof(int) + 16;
+    // up to ~67 KB of dynamic LDS at 64 materials: above the default cap, needs the attribute (once per process)
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_scatter_kernel),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    HIP_TRY(attr_rc);
     hipLaunchKernelGGL(bucket_count_kernel, dim3((unsigned)nblocks), dim3(BK_THREADS), lds_count, st, ids, (long long)n,
                        (int)n_materials, nblocks, blockhist);
     hipLaunchKernelGGL(bucket_scan_kernel, dim3((unsigned)n_materials), dim3(1024), 0, st, blockhist, nblocks, offs,
