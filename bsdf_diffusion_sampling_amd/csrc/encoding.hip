@@ -30,6 +30,7 @@ struct EncParams {
     float* out;
     long long n;
     int dim, bands, include_input, row_len;
+    int tile_rows;  // rows per workgroup: 128, fewer for very long rows so that the tile stays within 60 KB of LDS
     float freq[ENC_MAX_BANDS];
 };
 
@@ -41,8 +42,8 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
     const int dim = DIM ? DIM : p.dim, bands = BANDS ? BANDS : p.bands;
     const int row_len = DIM ? DIM * (1 + 2 * BANDS) : p.row_len;  // the specialised shapes include the input
     const int base = (DIM || p.include_input) ? dim : 0;
-    const long long row0 = (long long)blockIdx.x * ENC_TILE_ROWS;
-    const int rows = (int)min((long long)ENC_TILE_ROWS, p.n - row0);
+    const long long row0 = (long long)blockIdx.x * p.tile_rows;
+    const int rows = (int)min((long long)p.tile_rows, p.n - row0);
     // one thread per (row, dim): ONE sincosf per band gives the sin and the cos column
     for (int item = threadIdx.x; item < rows * dim; item += blockDim.x) {
         const int r = item / dim, d = item - r * dim;
@@ -95,9 +96,11 @@ extern "C" int bsdfd_positional_encoding(const float* x, int64_t n, int32_t dim,
             p.freq[b] = b < bands / 2 ? 1.0f + step * (float)b : hi - step * (float)(bands - 1 - b);
         }
     }
-    const long long blocks = (n + ENC_TILE_ROWS - 1) / ENC_TILE_ROWS;
+    p.tile_rows = ENC_TILE_ROWS;
+    while (p.tile_rows > 1 && (size_t)p.tile_rows * p.row_len * sizeof(float) > 60 * 1024) p.tile_rows /= 2;
+    const long long blocks = (n + p.tile_rows - 1) / p.tile_rows;
     if (blocks > 0x7fffffffLL) return bsdfd_fail_(BSDFD_EINVAL, "N too large for one launch");
-    const size_t lds = (size_t)ENC_TILE_ROWS * p.row_len * sizeof(float);
+    const size_t lds = (size_t)p.tile_rows * p.row_len * sizeof(float);
     const dim3 grid((unsigned)blocks), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dim == 2 && bands == 5 && include_input && log_sampling)       // velocity nets' conditioning

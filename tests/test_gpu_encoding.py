@@ -59,3 +59,12 @@ def test_errors_are_loud():
         positional_encoding_1(torch.zeros(4, 2, dtype=torch.float64).cuda(), 5)
     with pytest.raises(RuntimeError, match="bands"):
         positional_encoding_1(torch.zeros(4, 2).cuda(), 17)
+
+
+def test_longest_rows():
+    """dim 8 x 16 bands + input = 264 floats per row: the workgroup tile shrinks to stay within LDS."""
+    from bsdf_diffusion_sampling_amd.encoding import positional_encoding_1
+    x = (torch.rand(1000, 8, generator=torch.Generator().manual_seed(2)) * 2 - 1) * 1e-3   # 2^15 x: keep |arg| modest
+    got = positional_encoding_1(x.cuda(), 16).cpu()
+    want = _ref(x.double(), 16).float()
+    assert got.shape == (1000, 8 * 33) and (got - want).abs().max() < 5e-6
