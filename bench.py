@@ -317,6 +317,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(material, domain, T)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()  # orderly teardown: rank 0 is still printing / timing its side figures
         dist.destroy_process_group()
 
 
