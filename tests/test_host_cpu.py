@@ -230,3 +230,13 @@ def test_reference_modules_pack_to_the_shipped_weights():
     ships = W.load(W.shipped_path("bsdf_3", "spherical"))
     assert np.array_equal(fws.w_hidden, ships.w_hidden) and np.array_equal(fws.base_w1, ships.base_w1)
     assert not os.path.exists("/root/reference/rendering/utils/__pycache__")
+
+
+def test_mitsuba_adapter_fails_loudly_without_mitsuba():
+    """The optional adapter is import-guarded: with no Mitsuba in the image it must raise, not degrade."""
+    import importlib.util
+    if importlib.util.find_spec("mitsuba") is not None:
+        pytest.skip("mitsuba is installed")
+    from bsdf_diffusion_sampling_amd import mitsuba_adapter
+    with pytest.raises(RuntimeError, match="mitsuba / drjit are not installed"):
+        mitsuba_adapter.make_bsdf_class("disk")
