@@ -127,6 +127,14 @@ class NeuralBSDFCore:
     def pdf_t(self, wi: torch.Tensor, wo: torch.Tensor) -> torch.Tensor:
         return self.sampler.plugin_pdf(wi, wo, T=self.T, variant=self.VARIANT)
 
+    def sample_pdf_t(self, wi: torch.Tensor, wl: torch.Tensor, x0: Optional[torch.Tensor] = None,
+                     seed: Optional[int] = None, offset: int = 0):
+        """``sample_t(wi)`` and ``pdf_t(wi, wl)`` of the same intersections in one launch (a renderer with
+        next-event estimation asks both per path): -> (wo [N,3], pdf(wo) [N], pdf(wl) [N])."""
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        return self.sampler.plugin_sample_pdf(wi, wl, x0, T=self.T, variant=self.VARIANT, seed=seed, offset=offset)
+
     @staticmethod
     def apply_firefly_clamp(pdf: torch.Tensor, weight_lum: torch.Tensor, thr: float) -> torch.Tensor:
         """``pdf = where(lum(f/pdf) < thr, pdf, 0)`` (rendering/brdf_measured_disk.py:97-100 thr=30,

@@ -416,3 +416,16 @@ def test_fused_sample_pdf_equals_the_two_calls(stem, variant):
         import ctypes as C
         _lib.check(_lib.lib().bsdfd_plugin_sample_pdf(s._h, variant, C.c_void_p(wi.data_ptr()), None, None, 0, 0, n, T,
                                                       C.c_void_p(wo.data_ptr()), C.c_void_p(p.data_ptr()), None, None))
+
+
+def test_plugin_core_sample_pdf_t():
+    from bsdf_diffusion_sampling_amd.brdf_measured_disk import MyBSDF
+    plug = MyBSDF({"filename": "chm_orange_rgb", "measured": False})
+    rng = np.random.default_rng(3)
+    z, ph = rng.uniform(0.1, 1.0, size=5000), rng.uniform(0, 2 * np.pi, size=5000)
+    wi = _t(np.stack([np.sqrt(1 - z * z) * np.cos(ph), np.sqrt(1 - z * z) * np.sin(ph), z], 1))
+    wl = wi.flip(0).contiguous()
+    wo, po, pl = plug.sample_pdf_t(wi, wl, seed=7)
+    wo2, po2 = plug.sample_t(wi, seed=7)
+    assert torch.allclose(wo, wo2, atol=2e-6, rtol=0) and torch.allclose(po, po2, rtol=2e-5, atol=0)
+    assert torch.allclose(pl, plug.pdf_t(wi, wl), rtol=2e-5, atol=0)
