@@ -122,3 +122,28 @@ def test_create_destroy_does_not_leak_device_memory():
     cycle(300)
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, (free0, free1)                     # 300 leaked table sets would be ~400 MB
+
+
+def test_render_demo_in_plain_cpp(tmp_path):
+    """examples/render_demo.cpp: a whole render loop (primary -> fused sample+pdf -> ground-truth eval -> shade)
+    on the C ABI alone."""
+    from bsdf_diffusion_sampling_amd import weights as W
+    exe = str(tmp_path / "render_demo")
+    lib_dir = os.path.join(ROOT, "bsdf_diffusion_sampling_amd")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O2", "-Wno-unused-value", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "render_demo.cpp"), "-L", lib_dir, "-lbsdfd",
+                        f"-Wl,-rpath,{lib_dir}", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    weights = W.shipped_path("chm_orange_rgb", "disk")
+    gt = os.path.join(ROOT, "tests", "golden", "chm_orange_rgb.bsdf")
+    means = {}
+    for tag, arg in (("proxy", "-"), ("gt", gt)):
+        out = str(tmp_path / f"{tag}.ppm")
+        r = subprocess.run([exe, weights, arg, out, "128", "16"], capture_output=True, text=True)
+        assert r.returncode == 0 and "finite 1" in r.stdout, r.stdout + r.stderr
+        raw = open(out, "rb").read()
+        assert raw.startswith(b"P6\n128 128\n255\n") and len(raw) == 15 + 3 * 128 * 128
+        px = np.frombuffer(raw[15:], dtype=np.uint8).reshape(128, 128, 3).astype(np.float64)
+        means[tag] = px.mean((0, 1))
+    assert means["gt"][0] > 1.15 * means["gt"][2]                 # the measured film is orange
+    assert abs(means["proxy"][0] - means["proxy"][2]) < 0.25 * means["proxy"][0]   # the proxy is (nearly) grey
