@@ -238,3 +238,30 @@ def test_bucketing_rejects_bad_ids_and_sizes():
     big = torch.randint(0, 100, (5000,), generator=torch.Generator().manual_seed(0)).to(_dev())
     perm, counts = bucket_by_material(big, 100)
     assert torch.equal(perm.cpu(), torch.argsort(big.cpu(), stable=True)) and int(counts.sum()) == 5000
+
+
+def test_128Mi_queries_in_one_launch():
+    """BASELINE.json config 4 totals 128 Mi queries; one launch of that size must index correctly (64-bit row
+    arithmetic): the head and the tail of the batch equal small launches with the matching Philox offsets."""
+    from bsdf_diffusion_sampling_amd import weights as W
+    from bsdf_diffusion_sampling_amd.sampler import FlowSampler
+    s = FlowSampler(W.load(W.shipped_path("chm_orange_rgb", "disk")))
+    n = (1 << 27) + 5
+    base = _wi("disk", 1 << 20, 4)
+    wi = base.repeat((n >> 20) + 1, 1)[:n].contiguous()
+    wo = torch.empty_like(wi)
+    pdf = torch.empty(n, device=_dev())
+    s.plugin_sample(wi, None, T=1, seed=5, offset=0, out=(wo, pdf))
+    torch.cuda.synchronize()
+    k = 70000
+    head = s.plugin_sample(wi[:k].contiguous(), None, T=1, seed=5, offset=0)
+    tail = s.plugin_sample(wi[n - k:].contiguous(), None, T=1, seed=5, offset=n - k)
+    assert torch.equal(wo[:k], head[0]) and torch.equal(pdf[:k], head[1])
+    assert torch.equal(wo[n - k:], tail[0]) and torch.equal(pdf[n - k:], tail[1])
+    mid = 3 * (1 << 25) + 17
+    m = s.plugin_sample(wi[mid:mid + k].contiguous(), None, T=1, seed=5, offset=mid)
+    assert torch.equal(wo[mid:mid + k], m[0]) and torch.equal(pdf[mid:mid + k], m[1])
+    p = s.plugin_pdf(wi, wo, T=1)
+    assert torch.equal(p[n - k:], s.plugin_pdf(wi[n - k:].contiguous(), wo[n - k:].contiguous(), T=1))
+    del wi, wo, pdf, p
+    torch.cuda.empty_cache()
