@@ -26,6 +26,12 @@ echo "## full plugin calls with the native ground truth, 1 Mi queries (tools/plu
 python tools/plugin_overhead.py 2>/dev/null | grep sample
 echo "## stand-alone encoding pass (tools/enc_bench.py)"
 python tools/enc_bench.py 2>/dev/null | grep N=
+echo "## accuracy per precision mode on the golden cases, pdf error vs the fp64 oracle (tools/quick_gpu.py)"
+python tools/quick_gpu.py 2>/dev/null | grep "x_err"
+echo "## importance-sampling quality with the native ground truth (tools/is_quality.py)"
+python tools/is_quality.py 2>/dev/null | grep wi=
+echo "## 12-ball array scene, the reference's film size and sample count (tools/render_array.py)"
+python tools/render_array.py --passes 256 --width 1366 --height 1024 --out gpurun_out/array0_full 2>/dev/null | tail -1
 echo "## host call overhead (tools/host_overhead.py)"
 python tools/host_overhead.py 2>/dev/null | grep N=
 } > $OUT 2>&1
