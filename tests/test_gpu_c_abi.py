@@ -147,3 +147,24 @@ def test_render_demo_in_plain_cpp(tmp_path):
         means[tag] = px.mean((0, 1))
     assert means["gt"][0] > 1.15 * means["gt"][2]                 # the measured film is orange
     assert abs(means["proxy"][0] - means["proxy"][2]) < 0.25 * means["proxy"][0]   # the proxy is (nearly) grey
+
+
+def test_c_weight_loader_rejects_malformed_files(tmp_path):
+    """bsdfd_create_from_file: the C reader of the .bsdfw format fails loudly (BSDFD_EIO + message)."""
+    import ctypes as C
+    from bsdf_diffusion_sampling_amd import _lib
+    from bsdf_diffusion_sampling_amd import weights as W
+    good = open(W.shipped_path("chm_orange_rgb", "disk"), "rb").read()
+    L = _lib.lib()
+    for name, blob, msg in (("magic", b"XXXXXXXX" + good[8:], "not a BSDFWT01"), ("cut", good[:-8], "payload size"),
+                            ("tail", good + b"\0\0\0\0", "payload size"), ("short", good[:40], "BSDFWT01|header")):
+        p = tmp_path / (name + ".bsdfw")
+        p.write_bytes(blob)
+        h = C.c_void_p()
+        rc = L.bsdfd_create_from_file(str(p).encode(), 0, C.byref(h))
+        assert rc == 3 and not h.value, (name, rc)
+        import re
+        assert re.search(msg, L.bsdfd_last_error().decode()), L.bsdfd_last_error()
+    h = C.c_void_p()
+    assert L.bsdfd_create_from_file(W.shipped_path("chm_orange_rgb", "disk").encode(), 0, C.byref(h)) == 0 and h.value
+    L.bsdfd_destroy(h)

@@ -240,3 +240,29 @@ def test_mitsuba_adapter_fails_loudly_without_mitsuba():
     from bsdf_diffusion_sampling_amd import mitsuba_adapter
     with pytest.raises(RuntimeError, match="mitsuba / drjit are not installed"):
         mitsuba_adapter.make_bsdf_class("disk")
+
+
+def test_weight_file_loader_rejects_malformed_files(tmp_path):
+    """.bsdfw reader (weights.load): magic, header consistency, exact payload size."""
+    from bsdf_diffusion_sampling_amd import weights as W
+    good = open(W.shipped_path("chm_orange_rgb", "disk"), "rb").read()
+    cases = {
+        "short.bsdfw": (good[:40], "truncated header"),
+        "magic.bsdfw": (b"XXXXXXXX" + good[8:], "bad magic"),
+        "cut.bsdfw": (good[:-8], "truncated payload"),
+        "tail.bsdfw": (good + b"\0\0\0\0", "trailing bytes"),
+    }
+    # state_dim field (7th int32 of the header, after magic + 64-byte name) inconsistent with the domain
+    hdr = bytearray(good)
+    off = 8 + 64 + 6 * 4
+    hdr[off:off + 4] = (3).to_bytes(4, "little")
+    cases["sd.bsdfw"] = (bytes(hdr), "state_dim")
+    for name, (blob, msg) in cases.items():
+        p = tmp_path / name
+        p.write_bytes(blob)
+        with pytest.raises(ValueError, match=msg):
+            W.load(str(p))
+    fw = W.load(W.shipped_path("chm_orange_rgb", "disk"))
+    out = tmp_path / "round.bsdfw"
+    W.save(str(out), fw)
+    assert out.read_bytes() == good
