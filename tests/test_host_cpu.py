@@ -266,3 +266,33 @@ def test_weight_file_loader_rejects_malformed_files(tmp_path):
     out = tmp_path / "round.bsdfw"
     W.save(str(out), fw)
     assert out.read_bytes() == good
+
+
+def test_shard_and_bucket_properties_hypothesis():
+    """Property tests of the host-side partitioning: shards tile [0, n) in rank order with sizes differing by at
+    most one; bucketing is a stable permutation whose runs have the counted lengths."""
+    hyp = pytest.importorskip("hypothesis")
+    st = pytest.importorskip("hypothesis.strategies")
+    from bsdf_diffusion_sampling_amd.sharding import bucket_by_material, shard_range, shard_sizes
+
+    @hyp.settings(max_examples=200, deadline=None)
+    @hyp.given(st.integers(0, 10 ** 9), st.integers(1, 64))
+    def shards(n, world):
+        r = [shard_range(n, k, world) for k in range(world)]
+        assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        sizes = [b - a for a, b in r]
+        assert sizes == shard_sizes(n, world) and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    shards()
+
+    @hyp.settings(max_examples=50, deadline=None)
+    @hyp.given(st.lists(st.integers(0, 6), max_size=300))
+    def buckets(ids):
+        t = torch.tensor(ids, dtype=torch.int64)
+        perm, counts = bucket_by_material(t, 7)
+        assert sorted(perm.tolist()) == list(range(len(ids))) and counts.tolist() == [ids.count(m) for m in range(7)]
+        s = t[perm].tolist()
+        assert s == sorted(ids)
+        for m in range(7):  # stability: rows of one material keep their order
+            rows = [p for p in perm.tolist() if ids[p] == m]
+            assert rows == sorted(rows)
+    buckets()
