@@ -14,7 +14,8 @@ ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("BSDFD_LIB_PATH") or os.path.join(_HERE, "libbsdfd.so")  # override: A/B builds
 SRC_PATH = os.path.join(_HERE, "csrc", "bsdfd.hip")
 SRC_PATHS = [SRC_PATH, os.path.join(_HERE, "csrc", "wavefront.hip"), os.path.join(_HERE, "csrc", "encoding.hip"),
-             os.path.join(_HERE, "csrc", "measured.hip"), os.path.join(_HERE, "csrc", "bucket.hip")]  # translation units of libbsdfd.so
+             os.path.join(_HERE, "csrc", "measured.hip"), os.path.join(_HERE, "csrc", "bucket.hip"),
+             os.path.join(_HERE, "csrc", "clock.hip")]  # translation units of libbsdfd.so
 DEP_PATHS = SRC_PATHS + [os.path.join(_HERE, "csrc", "common.h")]
 INCLUDE_DIR = os.path.join(ROOT, "include")
 
@@ -32,7 +33,8 @@ EXPORTS = (
     "bsdfd_positional_encoding", "bsdfd_bucket_workspace_bytes", "bsdfd_bucket_by_material",
     "bsdfd_measured_create_from_file", "bsdfd_measured_destroy", "bsdfd_measured_get_info", "bsdfd_measured_eval",
     "bsdfd_measured_sample_weight",
-    "bsdfd_set_profiling", "bsdfd_profile_read", "bsdfd_last_kernel_ms", "bsdfd_last_error", "bsdfd_version",
+    "bsdfd_set_profiling", "bsdfd_profile_read", "bsdfd_last_kernel_ms", "bsdfd_shader_clock_mhz",
+    "bsdfd_last_error", "bsdfd_version",
 )
 
 
@@ -60,11 +62,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if (not force and os.path.exists(LIB_PATH)
             and os.path.getmtime(LIB_PATH) >= max([os.path.getmtime(hdr)] + [os.path.getmtime(f) for f in DEP_PATHS])):
         return LIB_PATH
+    # compile to a temporary name and rename into place: a concurrent process (another rank of a torchrun
+    # launch, a parallel test worker) never dlopens a half-written library
+    tmp = f"{LIB_PATH}.tmp.{os.getpid()}"
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed",
-           "-I", INCLUDE_DIR, *SRC_PATHS, "-o", LIB_PATH]
+           "-I", INCLUDE_DIR, *SRC_PATHS, "-o", tmp]
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB_PATH
 
 
@@ -117,12 +127,20 @@ def lib():
     L.bsdfd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]
     L.bsdfd_last_kernel_ms.argtypes = [vp]
     L.bsdfd_last_kernel_ms.restype = C.c_float
+    L.bsdfd_shader_clock_mhz.argtypes = [C.POINTER(C.c_double), vp]
     L.bsdfd_last_error.restype = C.c_char_p
     L.bsdfd_version.restype = C.c_char_p
     for name in EXPORTS:
         getattr(L, name)  # AttributeError if a declared symbol is missing
     _lib = L
     return L
+
+
+def shader_clock_mhz(stream=None) -> float:
+    """Shader clock (MHz) under the flow kernel's instruction mix (bsdfd_shader_clock_mhz, csrc/clock.hip)."""
+    mhz = C.c_double()
+    check(lib().bsdfd_shader_clock_mhz(C.byref(mhz), stream))
+    return mhz.value
 
 
 def check(rc: int) -> None:

@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -40,6 +41,9 @@
 
 #ifndef BSDFD_ABL
 #define BSDFD_ABL 0  // ablation bitmask for timing experiments under tools/ (always 0 in the product)
+#endif
+#ifndef BSDFD_EXP
+#define BSDFD_EXP 0  // experiment bitmask for the A/B builds of tools/ab_run.sh
 #endif
 
 namespace {
@@ -129,6 +133,49 @@ __device__ __forceinline__ float silu(float z) {  // base net: unscaled
 // hi/lo split of an fp32 value into two fp16-representable fp32 values (see header comment)
 __device__ __forceinline__ float hi_part(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFFE000u); }
 
+__device__ __forceinline__ float sub_f32(float a, float b) {
+#if (BSDFD_EXP & 1)  // keep x - hi a plain v_sub_f32 (no SLP v_pk_add_f32, no v_fma_mix fusion with the conversion)
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a - b;
+#endif
+}
+
+// sin and cos of a bounded argument (|a| <~ 1e3; the encoder's arguments are 2^b y with |y| <= pi, b <= 4): Cody-Waite
+// reduction by pi/2 in four parts (8 + 11 + 11 bits + remainder: k * part is exact, so is the first subtraction) and
+// the Cephes single-precision kernels on [-pi/4, pi/4]; max abs error 9.2e-8 (numpy prototype vs fp64, 8 M
+// arguments in [-100, 100]) against 6.9e-8 of a correctly rounded fp32 sin.  ~24 VALU instead of the ~3x longer
+// general-argument sincosf (whose Payne-Hanek branch these arguments never take).
+__device__ __forceinline__ void sincos_bounded(float a, float& s_out, float& c_out) {
+    const float k = rintf(a * 0.6366197466850281f);
+    float r = fmaf(k, -1.5703125f, a);
+    r = fmaf(k, -0.0004837512969970703f, r);
+    r = fmaf(k, -7.549533620476723e-08f, r);
+    r = fmaf(k, -2.5633440682570896e-12f, r);
+    const float z = r * r;
+    float p = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    p = fmaf(p, z, -1.6666654611e-1f);
+    const float s = fmaf(p * z, r, r);
+    float q = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    q = fmaf(q, z, 4.166664568298827e-2f);
+    const float c = fmaf(q * z, z, fmaf(z, -0.5f, 1.0f));
+    const int n = (int)k;
+    const float ss = (n & 1) ? c : s, cc = (n & 1) ? s : c;
+    s_out = __uint_as_float(__float_as_uint(ss) ^ ((unsigned)(n & 2) << 30));
+    c_out = __uint_as_float(__float_as_uint(cc) ^ ((unsigned)((n + 1) & 2) << 30));
+}
+
+__device__ __forceinline__ void sincos_enc(float a, float& s, float& c) {
+#if (BSDFD_EXP & 8)
+    if (__builtin_expect(fabsf(a) <= 1024.0f, 1)) sincos_bounded(a, s, c);
+    else sincosf(a, &s, &c);
+#else
+    sincosf(a, &s, &c);
+#endif
+}
+
 union Frag {  // one MFMA B fragment: the lane's 8 K-values of a chunk
     f16x8 v;
     f16x2 p[4];
@@ -139,8 +186,8 @@ __device__ __forceinline__ void split_pack(const float (&x)[4], f16x2& h01, f16x
         const float h0 = hi_part(x[0]), h1 = hi_part(x[1]), h2 = hi_part(x[2]), h3 = hi_part(x[3]);
         h01 = (f16x2){(_Float16)h0, (_Float16)h1};
         h23 = (f16x2){(_Float16)h2, (_Float16)h3};
-        l01 = (f16x2){(_Float16)(x[0] - h0), (_Float16)(x[1] - h1)};
-        l23 = (f16x2){(_Float16)(x[2] - h2), (_Float16)(x[3] - h3)};
+        l01 = (f16x2){(_Float16)sub_f32(x[0], h0), (_Float16)sub_f32(x[1], h1)};
+        l23 = (f16x2){(_Float16)sub_f32(x[2], h2), (_Float16)sub_f32(x[3], h3)};
     } else {
         h01 = (f16x2){(_Float16)x[0], (_Float16)x[1]};
         h23 = (f16x2){(_Float16)x[2], (_Float16)x[3]};
@@ -254,6 +301,13 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
         for (int i = threadIdx.x; i < p.L.total / 16; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
+#if (BSDFD_EXP & 4)  // static priority: co-resident workgroups of a CU (blocks b, b + 256, ...) get different levels
+    {
+        const unsigned lvl = (blockIdx.x >> 8) % 3u;
+        if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+        if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+    }
+#endif
 
     constexpr int KC = NM / 2;  // K chunks of 32 for the fp16 MFMA
     const int n_hidden = NH ? NH : p.n_hidden;
@@ -369,7 +423,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             const bool upper = (g >> 1) != 0;  // lanes 32..63: want cos; evaluate bands 3, 4
             float sv[3], cv[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) sincosf(ysel * (upper ? (float)(8 << k) : (float)(1 << k)), &sv[k], &cv[k]);
+            for (int k = 0; k < 3; ++k) sincos_enc(ysel * (upper ? (float)(8 << k) : (float)(1 << k)), sv[k], cv[k]);
             // swap(vdst, src): vdst[32..63] <-> src[0..31].  vdst = upper-half sin of band 3+k, src =
             // lower-half cos of band k: afterwards the lower half finds sin(band 3+k) in `src` and
             // the upper half finds cos(band k) in `vdst`.
@@ -509,7 +563,11 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                 }
             } else {
                 float sp, cp;
+#if (BSDFD_EXP & 16)
+                sincos_enc(x1, sp, cp);
+#else
                 sincosf(x1, &sp, &cp);  // net input [theta, sin phi, cos phi], mlp_brdf_sampling.py:119-121
+#endif
                 const float bs = sel4(g, x0, sp, cp, alpha);
                 const float bt = sel4(g, 0.0f, cp, -sp, 0.0f);  // d/dphi of the input
 #pragma unroll
@@ -612,6 +670,9 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                         f32x4 a[NM], a0[NM], a1[NM];
 #pragma unroll
                         for (int mo = 0; mo < NM; ++mo) { a[mo] = zero4; a0[mo] = zero4; a1[mo] = zero4; }
+#if (BSDFD_EXP & 2)
+                        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
                         for (int kc = 0; kc < KC; ++kc) {
                             f16x8 wh[NM], wl[NM];
@@ -643,6 +704,9 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 #endif
                             }
                         }
+#if (BSDFD_EXP & 2)
+                        __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
                         for (int mo = 0; mo < NM; ++mo) { z[mo] = a[mo]; zt0[mo] = a0[mo]; zt1[mo] = a1[mo]; }
                     } else {
@@ -702,8 +766,13 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                 pdf_sa = (ok ? pdf : 0.0f) * oz;
             } else {  // rendering/brdf_measured_spherical.py:79-91, bsdf_myresult.py:69-84
                 float st, ct, sp, cp;
+#if (BSDFD_EXP & 16)
+                sincos_enc(x0, st, ct);
+                sincos_enc(x1, sp, cp);
+#else
                 sincosf(x0, &st, &ct);
                 sincosf(x1, &sp, &cp);
+#endif
                 if (!(st > 0.00005f)) pdf = 0.0f;
                 if (p.io == IO_PLUGIN && !(ct > 0.0f)) pdf = 0.0f;
                 ox = cp * st; oy = sp * st; oz = ct;
@@ -755,8 +824,12 @@ struct bsdfd_ctx {
     const void* kfun[3];
     ImgLayout L;
     char* d_img;
-    // profiling: a ring of HIP event pairs recorded on the launch stream around every launch
+    // profiling: a ring of HIP event pairs recorded on the launch stream around every launch.  Everything
+    // above this line is immutable after create; the profiling state below is guarded by `prof_mu`, so the
+    // handle stays re-entrant across host threads / streams with profiling on (launches that are being timed
+    // serialise on the mutex for the two hipEventRecord calls only).
     static constexpr int RING = 64;
+    std::mutex prof_mu;
     bool profiling;
     hipEvent_t ev0[RING], ev1[RING];
     bool pending[RING];
@@ -960,7 +1033,8 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     const int mode = op == OP_SAMPLES_ONLY ? 0 : (op == OP_SAMPLE_PDF ? 2 : 1);
     int per_cu = h->per_cu[mode];
     if (per_cu < 1) per_cu = 1;
-    static const int per_cu_override = [] {  // tuning knobs (tools/tscan.py, tools/nscan.py), read once
+#ifdef BSDFD_TUNING  // tools-only builds (tools/ab_build.sh ... "-DBSDFD_TUNING"): grid-shape knobs for tools/tscan.py, nscan.py
+    static const int per_cu_override = [] {
         const char* ov = std::getenv("BSDFD_BLOCKS_PER_CU");
         return ov ? std::atoi(ov) : 0;
     }();
@@ -969,6 +1043,9 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
         return ov ? std::atoi(ov) : -1;
     }();
     if (per_cu_override > 0) per_cu = per_cu_override;
+#else
+    constexpr int cl_override = -1;
+#endif
     const long long cap = (long long)h->num_cu * per_cu * 4;
     // tiles per wave and chunk: 8 when that still leaves >= `min_chunks` workgroup-chunks, else fewer
     auto pick_cl = [&](long long ntiles, long long min_chunks) {
@@ -1012,17 +1089,21 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     }
     dim3 grid((unsigned)nblocks), block(threads);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int slot = -1;
-    if (h->profiling) {
-        slot = (int)(h->n_rec % bsdfd_ctx::RING);
-        if (h->pending[slot]) HIP_TRY(harvest(h, slot));
-        HIP_TRY(hipEventRecord(h->ev0[slot], s));
-    }
     void* args[] = {const_cast<KParams*>(&kp)};
+    std::unique_lock<std::mutex> prof_lock(h->prof_mu, std::defer_lock);
+    int slot = -1;
+    if (h->profiling) {  // (a racy read is fine: the flag is re-read under the lock)
+        prof_lock.lock();
+        if (h->profiling) {
+            slot = (int)(h->n_rec % bsdfd_ctx::RING);
+            if (h->pending[slot]) HIP_TRY(harvest(h, slot));
+            HIP_TRY(hipEventRecord(h->ev0[slot], s));
+        }
+    }
     hipError_t e = hipLaunchKernel(h->kfun[mode], grid, block, args, (size_t)h->L.total, s);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) return fail(BSDFD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
-    if (h->profiling) {
+    if (slot >= 0) {
         HIP_TRY(hipEventRecord(h->ev1[slot], s));
         h->pending[slot] = true;
         h->n_rec++;
@@ -1264,6 +1345,7 @@ int bsdfd_flow_samples_only(bsdfd_handle h, const float* omega_i, const float* x
 
 int bsdfd_set_profiling(bsdfd_handle h, int32_t enable) {
     if (!h) return fail(BSDFD_EINVAL, "null handle");
+    std::lock_guard<std::mutex> lock(h->prof_mu);
     for (int i = 0; i < bsdfd_ctx::RING; ++i)
         if (h->pending[i]) HIP_TRY(harvest(h, i));
     h->profiling = enable != 0;
@@ -1275,6 +1357,7 @@ int bsdfd_set_profiling(bsdfd_handle h, int32_t enable) {
 
 int bsdfd_profile_read(bsdfd_handle h, int64_t* n_launches, double* total_ms) {
     if (!h) return fail(BSDFD_EINVAL, "null handle");
+    std::lock_guard<std::mutex> lock(h->prof_mu);
     // harvest in launch order so last_ms is the most recent launch
     for (long long k = h->n_done; k < h->n_rec; ++k) {
         const int slot = (int)(k % bsdfd_ctx::RING);
@@ -1286,8 +1369,13 @@ int bsdfd_profile_read(bsdfd_handle h, int64_t* n_launches, double* total_ms) {
 }
 
 float bsdfd_last_kernel_ms(bsdfd_handle h) {
-    if (!h || !h->profiling || h->n_rec == 0) return -1.0f;
+    if (!h) return -1.0f;
+    {
+        std::lock_guard<std::mutex> lock(h->prof_mu);
+        if (!h->profiling || h->n_rec == 0) return -1.0f;
+    }
     if (bsdfd_profile_read(h, nullptr, nullptr) != BSDFD_OK) return -1.0f;
+    std::lock_guard<std::mutex> lock(h->prof_mu);
     return h->last_ms;
 }
 

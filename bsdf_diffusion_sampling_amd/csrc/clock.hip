@@ -1,0 +1,92 @@
+// clock.hip — shader-clock probe for the issue-bound roofline entry of bench.py.
+//
+// The flow kernel is bound by VALU + MFMA issue on each SIMD, so its roofline is stated in
+// shader cycles per (16-query tile x Euler step); turning a measured launch duration into cycles needs the
+// clock the chip sustains UNDER A SIMILAR LOAD (an MI355X runs this instruction mix at ~2.0-2.2 GHz, not at
+// the 2.4 GHz maximum: MI355X_MICROARCH.md "DVFS give-back").  The probe fills every CU with waves that
+// issue the flow kernel's per-layer mix (fp16 MFMAs + fp32 VALU + transcendentals) for a few milliseconds and
+// divides the shader-cycle counter (s_memtime) delta of one wave by the HIP-event duration of the launch.
+#include <hip/hip_runtime.h>
+
+#include "bsdfd.h"
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256, 3) void clock_probe_kernel(int iters, unsigned long long* cycles, float* sink) {
+    float a[8];
+    for (int j = 0; j < 8; ++j) a[j] = 0.25f + 1e-3f * (float)(threadIdx.x & 63) + 0.125f * (float)j;
+    f16x8 h0, h1;
+    for (int j = 0; j < 8; ++j) { h0[j] = (_Float16)(a[j] * 0.01f); h1[j] = (_Float16)(0.02f - a[j] * 0.01f); }
+    f32x4 c[6];
+    for (int j = 0; j < 6; ++j) c[j] = (f32x4){a[0], a[1], a[2], a[3]} * 1e-3f;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int m = 0; m < 18; ++m) c[m % 6] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, h1, c[m % 6], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {  // one hidden unit's worth of activation math (sigmoid, SiLU', hi/lo split)
+            const float z = c[u % 6][u & 3] * 1e-3f + a[u];
+            const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
+            const float hs = z * s;
+            const float g = fmaf(hs, fmaf(s, 0.6931472f, -0.6931472f), s);
+            const float hi = __uint_as_float(__float_as_uint(hs) & 0xFFFFE000u);
+            a[u] = (hs - hi) + g * 0.5f + hi * 1e-3f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { h0[j] = (_Float16)(a[j] * 0.01f); }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float acc = 0.f;
+    for (int j = 0; j < 8; ++j) acc += a[j];
+    for (int j = 0; j < 6; ++j) acc += c[j][0] + c[j][3];
+    if (acc == 12345.678f) sink[0] = acc;  // keeps the loop alive
+    if (blockIdx.x == 0 && threadIdx.x == 0) *cycles = (unsigned long long)(t1 - t0);
+}
+
+}  // namespace
+
+extern "C" int bsdfd_shader_clock_mhz(double* mhz, void* hip_stream) {
+    if (!mhz) return bsdfd_fail_(BSDFD_EINVAL, "null argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    unsigned long long* d_cyc = nullptr;
+    float* d_sink = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cyc), sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_sink), sizeof(float)));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const int grid = prop.multiProcessorCount * 3;  // 3 workgroups of 4 waves per CU = the flow kernel's occupancy
+    double best = 0.0;
+    int rc = BSDFD_OK;
+    // two launches: the first also absorbs the clock ramp after an idle period
+    for (int rep = 0; rep < 2 && rc == BSDFD_OK; ++rep) {
+        const int iters = rep == 0 ? 2000 : 6000;  // ~1.5 ms and ~4.5 ms
+        hipError_t e = hipEventRecord(e0, s);
+        if (e == hipSuccess) {
+            clock_probe_kernel<<<grid, 256, 0, s>>>(iters, d_cyc, d_sink);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipEventRecord(e1, s);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long cyc = 0;
+        if (e == hipSuccess) e = hipMemcpy(&cyc, d_cyc, sizeof cyc, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = bsdfd_fail_(BSDFD_EHIP, std::string("clock probe: ") + hipGetErrorString(e));
+        else if (ms > 0.f) best = (double)cyc / ((double)ms * 1e3);  // cycles per microsecond = MHz
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(d_cyc);
+    (void)hipFree(d_sink);
+    *mhz = best;
+    return rc;
+}

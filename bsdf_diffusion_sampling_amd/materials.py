@@ -125,7 +125,11 @@ class MaterialTable:
 
     def _buckets(self, material_id, extra_bins: int = 0):
         if isinstance(material_id, tuple):  # a plan from bucket(): (perm, counts)
-            return material_id
+            perm, counts = material_id
+            if (not isinstance(perm, torch.Tensor) or perm.dtype != torch.int64 or perm.dim() != 1
+                    or len(counts) < len(self) or sum(counts) != perm.shape[0] or min(counts, default=0) < 0):
+                raise ValueError("not a bucketing plan of this table: expected (perm int64 [N], counts) from bucket()")
+            return perm, list(counts)
         if material_id.dtype != torch.int64:
             material_id = material_id.long()
         perm, counts = bucket_by_material(material_id, len(self) + extra_bins)
@@ -133,6 +137,20 @@ class MaterialTable:
         if sum(counts) != material_id.shape[0]:
             raise ValueError(f"material ids must be in [0, {len(self) + extra_bins})")
         return perm, counts
+
+    def _plan(self, material_id, n_rows: int):
+        """(rows, counts, seg_end): `rows` = the bucketed order of the lanes that carry a material (lanes of the
+        plan's extra bins sort behind them and are not evaluated), `counts` per material."""
+        perm, counts = self._buckets(material_id)
+        if perm.shape[0] != n_rows:
+            raise ValueError(f"the bucketing plan covers {perm.shape[0]} rows, the batch has {n_rows}")
+        counts = counts[: len(self)]
+        n_mat = sum(counts)
+        rows = perm if n_mat == n_rows else perm[:n_mat]
+        return rows, counts, list(__import__("itertools").accumulate(counts))
+
+    def _chk_in(self, t, cols, name, n=None):
+        return self.samplers[0]._chk(t, cols, name, n)
 
     def bucket(self, material_id: torch.Tensor, extra_bins: int = 0):
         """Bucket a wavefront once and reuse the plan for its sample() and pdf() calls (a renderer asks both
@@ -147,13 +165,14 @@ class MaterialTable:
         """wi [N,3], material_id [N] -> (wo [N,3], pdf_sa [N]) in the callers' order.
         The Philox counter of a query is ``offset + its row in the bucketed (sorted-by-material)
         array``, identical for the segmented and the per-bucket path."""
-        perm, counts = self._buckets(material_id)
-        wi_s = wi[perm].contiguous()
-        x0_s = None if x0 is None else x0[perm].contiguous()
+        wi = self._chk_in(wi, 3, "wi")
+        x0 = self._chk_in(x0, 2, "x0", wi.shape[0])
+        rows, counts, seg_end = self._plan(material_id, wi.shape[0])
+        wi_s = wi[rows].contiguous()
+        x0_s = None if x0 is None else x0[rows].contiguous()
         wo_s = torch.empty_like(wi_s)
         pdf_s = torch.empty(wi_s.shape[0], dtype=torch.float32, device=wi.device)
         if segmented:
-            seg_end = list(__import__("itertools").accumulate(counts))
             with torch.cuda.device(wi.device):
                 for (dom, w, nh, prec, Tm, var), members in self._groups().items():
                     self._multi("sample", members, seg_end, Tm if T is None else T, var, wi_s, x0_s, seed, offset,
@@ -169,25 +188,27 @@ class MaterialTable:
                                                T=self.T[m] if T is None else T, variant=self.variant[m],
                                                seed=seed, offset=offset + lo, out=(wo_s[sl], pdf_s[sl]))
                 lo += n
-        wo = torch.empty_like(wo_s)
-        pdf = torch.empty_like(pdf_s)
-        wo[perm] = wo_s
-        pdf[perm] = pdf_s
+        mk = torch.empty if rows.shape[0] == wi.shape[0] else torch.zeros  # lanes without a material: zeros
+        wo = mk(wi.shape, dtype=torch.float32, device=wi.device)
+        pdf = mk(wi.shape[0], dtype=torch.float32, device=wi.device)
+        wo[rows] = wo_s
+        pdf[rows] = pdf_s
         return wo, pdf
 
     def sample_pdf(self, material_id, wi: torch.Tensor, wl: torch.Tensor, seed: int = 0, offset: int = 0,
                    T: Optional[int] = None, x0: Optional[torch.Tensor] = None, return_bucketed: bool = False):
         """sample(wi) and pdf(wi, wl) for the same material-tagged intersections, one launch per kernel
         signature (``bsdfd_plugin_sample_pdf_multi``) -> (wo [N,3], pdf(wo) [N], pdf(wl) [N]) in the callers' order."""
-        perm, counts = self._buckets(material_id)
-        n_mat = sum(counts[: len(self)])            # lanes behind it (extra bins) carry no material
-        rows = perm[:n_mat]
+        wi = self._chk_in(wi, 3, "wi")
+        wl = self._chk_in(wl, 3, "wl", wi.shape[0])
+        x0 = self._chk_in(x0, 2, "x0", wi.shape[0])
+        rows, counts, seg_end = self._plan(material_id, wi.shape[0])  # lanes of the extra bins carry no material
+        n_mat = rows.shape[0]
         wi_s, wl_s = wi[rows].contiguous(), wl[rows].contiguous()
         x0_s = None if x0 is None else x0[rows].contiguous()
         wo_s = torch.empty_like(wi_s)
         po_s = torch.empty(n_mat, dtype=torch.float32, device=wi.device)
         pl_s = torch.empty_like(po_s)
-        seg_end = list(__import__("itertools").accumulate(counts[: len(self)]))
         with torch.cuda.device(wi.device):
             for (dom, w, nh, prec, Tm, var), members in self._groups().items():
                 self._multi("sample_pdf", members, seg_end, Tm if T is None else T, var, wi_s, (x0_s, wl_s), seed,
@@ -206,11 +227,12 @@ class MaterialTable:
 
     def pdf(self, material_id: torch.Tensor, wi: torch.Tensor, wo: torch.Tensor, T: Optional[int] = None,
             segmented: bool = True):
-        perm, counts = self._buckets(material_id)
-        wi_s, wo_s = wi[perm].contiguous(), wo[perm].contiguous()
+        wi = self._chk_in(wi, 3, "wi")
+        wo = self._chk_in(wo, 3, "wo", wi.shape[0])
+        rows, counts, seg_end = self._plan(material_id, wi.shape[0])
+        wi_s, wo_s = wi[rows].contiguous(), wo[rows].contiguous()
         pdf_s = torch.empty(wi_s.shape[0], dtype=torch.float32, device=wi.device)
         if segmented:
-            seg_end = list(__import__("itertools").accumulate(counts))
             with torch.cuda.device(wi.device):
                 for (dom, w, nh, prec, Tm, var), members in self._groups().items():
                     self._multi("pdf", members, seg_end, Tm if T is None else T, var, wi_s, wo_s, 0, 0, None, pdf_s)
@@ -223,6 +245,7 @@ class MaterialTable:
                 self.samplers[m].plugin_pdf(wi_s[sl], wo_s[sl], T=self.T[m] if T is None else T,
                                             variant=self.variant[m], out=pdf_s[sl])
                 lo += n
-        pdf = torch.empty_like(pdf_s)
-        pdf[perm] = pdf_s
+        pdf = (torch.empty if rows.shape[0] == wi.shape[0] else torch.zeros)(wi.shape[0], dtype=torch.float32,
+                                                                             device=wi.device)
+        pdf[rows] = pdf_s
         return pdf

@@ -78,6 +78,14 @@ class FlowSampler:
             raise RuntimeError(f"{name} must be contiguous")
         return t
 
+    def _chk1(self, t: torch.Tensor, n: int, name: str):
+        """A caller-supplied 1-D output (pdf [N]): the kernel writes N floats through its raw pointer."""
+        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.device != self.device:
+            raise RuntimeError(f"{name} must be a CUDA (HIP) tensor on {self.device}")
+        if t.dtype != torch.float32 or t.dim() != 1 or t.shape[0] != n or not t.is_contiguous():
+            raise RuntimeError(f"{name} must be a contiguous float32 tensor of shape [{n}], got {t.dtype} {tuple(t.shape)}")
+        return t
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -139,7 +147,7 @@ class FlowSampler:
             wo = torch.empty((n, 3), dtype=torch.float32, device=self.device)
             pdf = torch.empty((n,), dtype=torch.float32, device=self.device)
         else:
-            wo, pdf = self._chk(out[0], 3, "out wo", n), out[1]
+            wo, pdf = self._chk(out[0], 3, "out wo", n), self._chk1(out[1], n, "out pdf")
         with torch.cuda.device(self.device):
             _lib.check(self._L.bsdfd_plugin_sample(self._h, variant, _ptr(wi), _ptr(x0), seed, offset, n, T,
                                                    _ptr(wo), _ptr(pdf), self._stream()))
@@ -158,7 +166,8 @@ class FlowSampler:
             pdf_o = torch.empty((n,), dtype=torch.float32, device=self.device)
             pdf_l = torch.empty((n,), dtype=torch.float32, device=self.device)
         else:
-            wo, pdf_o, pdf_l = self._chk(out[0], 3, "out wo", n), out[1], out[2]
+            wo, pdf_o, pdf_l = (self._chk(out[0], 3, "out wo", n), self._chk1(out[1], n, "out pdf(wo)"),
+                                self._chk1(out[2], n, "out pdf(wl)"))
         with torch.cuda.device(self.device):
             _lib.check(self._L.bsdfd_plugin_sample_pdf(self._h, variant, _ptr(wi), _ptr(x0), _ptr(wl), seed, offset,
                                                        n, T, _ptr(wo), _ptr(pdf_o), _ptr(pdf_l), self._stream()))
@@ -169,7 +178,7 @@ class FlowSampler:
         wi = self._chk(wi, 3, "wi")
         n = wi.shape[0]
         wo = self._chk(wo, 3, "wo", n)
-        pdf = torch.empty((n,), dtype=torch.float32, device=self.device) if out is None else out
+        pdf = torch.empty((n,), dtype=torch.float32, device=self.device) if out is None else self._chk1(out, n, "out pdf")
         with torch.cuda.device(self.device):
             _lib.check(self._L.bsdfd_plugin_pdf(self._h, variant, _ptr(wi), _ptr(wo), n, T, _ptr(pdf),
                                                 self._stream()))

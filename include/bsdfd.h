@@ -16,7 +16,8 @@
  *   - return value 0 = ok, otherwise a BSDFD_E* code; bsdfd_last_error() returns a
  *     thread-local message (the Python host raises RuntimeError with it);
  *   - a handle is immutable after create and bound to the device current at create;
- *     calls are re-entrant across streams.
+ *     calls are re-entrant across host threads and streams (the optional launch-timing
+ *     counters of bsdfd_set_profiling are the only mutable state and are mutex-guarded).
  */
 #ifndef BSDFD_H
 #define BSDFD_H
@@ -163,6 +164,12 @@ int bsdfd_flow_samples_only(bsdfd_handle h, const float* omega_i, const float* x
 int bsdfd_set_profiling(bsdfd_handle h, int32_t enable);
 int bsdfd_profile_read(bsdfd_handle h, int64_t* n_launches, double* total_ms);
 float bsdfd_last_kernel_ms(bsdfd_handle h);
+
+/* Shader clock (MHz) the chip sustains under the flow kernel's instruction mix: a ~6 ms probe launch on every
+ * CU, shader-cycle counter of one wave / HIP-event duration (csrc/clock.hip).  Measurement only: bench.py
+ * uses it to state kernel time in shader cycles per (16-query tile x Euler step) next to the instruction-issue
+ * model of that loop (the "issue-bound" roofline entry).  No counterpart in the reference. */
+int bsdfd_shader_clock_mhz(double* mhz, void* hip_stream);
 
 /* Stand-alone positional encoding = the reference's positional_encoding_1 (rendering/utils/model.py:9-57):
  * x [N,dim] -> out [N, dim * (include_input + 2 * bands)] = cat([x], sin(f_0 x), cos(f_0 x), ...), f = 2^b

@@ -1,0 +1,72 @@
+"""bench.py end to end on the 1-GPU test box: the judged line at N = 1, and the self-launching N = 2 path
+(`python bench.py --gpus 2` starts its own ranks as child processes; BSDFD_BENCH_BACKEND=gloo lets the two ranks
+share the one GPU and stages the gather through host memory, so the whole N > 1 control flow — rendezvous, barrier +
+max-over-ranks timing, the three gather modes, rank/device report — runs without RCCL)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAST = ["--steps", "2", "--warmup", "1", "--passes-per-step", "2", "--settle-ms", "20", "--no-cpu-baseline", "--no-secondary"]
+
+
+def _run(args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env,
+                       timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _check_contract(d, n_gpus, workload):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == n_gpus and d["unit"] == "Msamples/s" and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["config"]["workload"] == workload and d["value"] > 0
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # value is consistent with the line's own step time and step size
+    c = d["config"]
+    assert abs(d["value"] - c["queries_per_step"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-6
+    assert c["queries_per_step"] == c["queries_per_wavefront_per_gpu"] * c["passes_per_step"] * n_gpus
+
+
+def test_bench_line_single_gpu_with_secondary_and_cpu_baseline():
+    d = _run(["--gpus", "1", "--steps", "3", "--warmup", "1"])
+    _check_contract(d, 1, "disk_1Mi_T8")
+    assert d["config"]["timed_region_s"] >= 0.45                     # sized at setup, whatever --steps is
+    ib = d["roofline"]["issue_bound"]
+    assert 1000 < ib["shader_clock_mhz"] < 2500 and 0.5 < ib["frac_of_issue_bound"] < 1.3, ib
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["all_cores"]["value"] > 0 and cb["all_cores"]["cores"] >= cb["cores"]
+    for name in ("disk_1Mi_T4", "spherical_16Mi_T8", "mixed_16Mi", "teacher_64x6_4Mi_T128"):
+        s = d["secondary"][name]
+        assert "error" not in s, s
+        assert s["value"] > 0 and 0 < s["frac"] < 1
+    assert d["encoding_pass"]["bound"] == "hbm" and d["encoding_pass"]["frac"] > 0.3
+
+
+@pytest.mark.parametrize("workload", ["disk_1Mi_T8", "mixed_16Mi"])
+def test_bench_self_launches_two_ranks(workload):
+    one = _run(["--gpus", "1", "--workload", workload] + FAST)
+    _check_contract(one, 1, workload)
+    two = _run(["--gpus", "2", "--workload", workload] + FAST, {"BSDFD_BENCH_BACKEND": "gloo"})
+    _check_contract(two, 2, workload)
+    ranks = two["config"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and all(r["device"] == 0 for r in ranks)  # both on the one GPU here
+    mg = two["multi_gpu"]
+    assert mg["judged"] == "final" and abs(mg["Msamples_per_s_final_gather"] - two["value"]) < 1e-9 * two["value"] + 1e-9
+    assert mg["Msamples_per_s_no_gather"] > 0 and mg["Msamples_per_s_gather_every_step_overlapped"] > 0
+    assert mg["gather_bytes_per_rank"] == two["config"]["queries_per_wavefront_per_gpu"] * 16
+    # two ranks time-share one GPU: the job-level rate cannot exceed ~1x the single-rank rate (and is not far below it)
+    assert 0.3 * one["value"] < two["value"] < 1.3 * one["value"], (one["value"], two["value"])

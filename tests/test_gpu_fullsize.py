@@ -125,6 +125,46 @@ def test_mixed_material_table_matches_per_material_calls():
     assert torch.isfinite(wo2).all() and torch.equal(wo2, wo3) and torch.equal(pdf2, pdf3)
 
 
+def test_plan_with_extra_bins_serves_sample_and_pdf():
+    """A bucketing plan with `extra_bins` (a renderer's floor hits / misses: lanes that carry no material) may be
+    passed to sample(), pdf() and sample_pdf(): the material lanes equal a table call on those lanes alone, the
+    other lanes come back as ZEROS (never uninitialised memory), segmented or not; malformed plans are rejected."""
+    from bsdf_diffusion_sampling_amd.materials import MaterialTable
+    stems = ["aniso_miro_7_rgb_disk", "chm_orange_rgb_disk", "vch_silk_blue_rgb_disk"]
+    tab = MaterialTable(stems)
+    n = 20000
+    wi = _wi("disk", n, 5)
+    ids = torch.randint(0, len(stems) + 2, (n,), generator=torch.Generator().manual_seed(2)).to(_dev())
+    plan = tab.bucket(ids, extra_bins=2)
+    mat = ids < len(stems)
+    assert 0 < int(mat.sum()) < n
+    for seg in (True, False):
+        wo, pdf = tab.sample(plan, wi, seed=4, offset=7, segmented=seg)
+        assert torch.count_nonzero(wo[~mat]) == 0 and torch.count_nonzero(pdf[~mat]) == 0
+        assert torch.isfinite(wo).all() and torch.isfinite(pdf).all()
+        assert torch.allclose((wo[mat] ** 2).sum(1), torch.ones(int(mat.sum()), device=_dev()), atol=1e-4)
+        # the material lanes keep their relative (bucketed) order when the other lanes are dropped, so a table call on
+        # them alone sees the same Philox counters
+        wo_m, pdf_m = tab.sample(ids[mat], wi[mat].contiguous(), seed=4, offset=7, segmented=seg)
+        assert torch.equal(wo[mat], wo_m) and torch.equal(pdf[mat], pdf_m)
+        p = tab.pdf(plan, wi, wo, segmented=seg)
+        assert torch.count_nonzero(p[~mat]) == 0
+        assert torch.equal(p[mat], tab.pdf(ids[mat], wi[mat].contiguous(), wo[mat].contiguous(), segmented=seg))
+    wl = _wi("disk", n, 6)
+    wo_f, po_f, pl_f = tab.sample_pdf(plan, wi, wl, seed=4, offset=7)
+    assert torch.count_nonzero(wo_f[~mat]) == 0 and torch.count_nonzero(pl_f[~mat]) == 0
+    with pytest.raises(ValueError):
+        tab.sample((plan[0][:-1], plan[1]), wi)                       # perm and counts disagree
+    with pytest.raises(ValueError):
+        tab.sample(plan, wi[:100].contiguous())                       # plan of another batch size
+    with pytest.raises(ValueError):
+        tab.pdf((plan[0], plan[1][:2]), wi, wo)                       # fewer bins than materials
+    with pytest.raises(RuntimeError):
+        tab.sample(plan, wi.double())                                 # inputs are validated before pointer arithmetic
+    with pytest.raises(RuntimeError):
+        tab.pdf(plan, wi, wo.t().contiguous().t())                    # non-contiguous
+
+
 def test_mixed_domains_and_more_than_64_buckets():
     """Disk + spherical + full-sphere materials interleaved by id (runs of adjacent buckets per kernel
     signature), and a table of 77 materials (> 64 buckets: the ABI splits the launch)."""

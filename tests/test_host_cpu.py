@@ -296,3 +296,20 @@ def test_shard_and_bucket_properties_hypothesis():
             rows = [p for p in perm.tolist() if ids[p] == m]
             assert rows == sorted(rows)
     buckets()
+
+
+def test_bench_self_launch_fails_loudly_without_gpus():
+    """`python bench.py --gpus 2` outside a launcher starts its own ranks as child processes and returns their
+    exit code: on this GPU-less container the ranks die at torch.cuda.set_device, and the parent must report
+    failure (non-zero, no hang, no JSON line) instead of a fabricated number."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["BSDFD_BENCH_BACKEND"] = "gloo"
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a GPU-less host")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

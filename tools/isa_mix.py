@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Instruction mix of the Euler-step loop of one flow_kernel instantiation, from the gfx950 assembly.
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -S --cuda-device-only -I include \
+        bsdf_diffusion_sampling_amd/csrc/bsdfd.hip -o /tmp/bsdfd.s
+    python tools/isa_mix.py /tmp/bsdfd.s 'flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E'
+
+Finds the kernel's body, takes the innermost loop that holds the most MFMAs (the Euler step: a label
+and the backward branch to it) and prints the count per mnemonic, the issue-cycle estimate at the rates
+of tools/ubench/RESULTS.md, and the kernel's register / scratch footprint.  Used for the
+"VALU instructions per tile-step" column of DESIGN.md §4 and the issue-bound roofline of bench.py.
+"""
+import collections
+import json
+import re
+import sys
+
+# measured issue cost, shader cycles per wave64 instruction per SIMD (tools/ubench/RESULTS.md)
+COST = {"v_mfma_f32_16x16x32_f16": 16.2, "v_mfma_f32_16x16x4_f32": 32.0, "v_mfma_f32_32x32x16_f16": 32.1,
+        "v_exp_f32": 7.0, "v_rcp_f32": 7.2, "v_log_f32": 7.0, "v_sqrt_f32": 7.0, "v_sin_f32": 7.0, "v_cos_f32": 7.0,
+        "v_rsq_f32": 7.0, "v_exp_f16": 7.0, "v_rcp_f16": 7.2,
+        "v_cvt_pk_f16_f32": 3.7, "v_cvt_pkrtz_f16_f32": 4.4, "v_perm_b32": 4.3, "v_cvt_f32_f16": 3.6,
+        "v_fma_mix_f32": 7.3, "v_fma_mixlo_f16": 7.3, "v_fma_mixhi_f16": 7.3}
+PK = 3.7      # v_pk_{fma,mul,add}_f32
+PLAIN = 2.4   # any other VALU
+
+
+def cost(m):
+    if m in COST:
+        return COST[m]
+    if m.startswith("v_pk_") and m.endswith("_f32"):
+        return PK
+    if m.startswith("v_"):
+        return PLAIN
+    return 0.0
+
+
+def kernel_body(lines, key):
+    start = None
+    for i, l in enumerate(lines):
+        if l.startswith("_Z") and key in l and l.split(";")[0].rstrip().endswith(":"):
+            start = i
+            break
+    if start is None:
+        raise SystemExit(f"kernel matching {key!r} not found")
+    for j in range(start, len(lines)):
+        if lines[j].strip().startswith("s_endpgm"):
+            return lines[start:j + 1]
+    return lines[start:]
+
+
+def loops(body):
+    """(first, last) line indices of every label .. backward-branch pair."""
+    labels = {}
+    out = []
+    for i, l in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            labels[m.group(1)] = i
+        m = re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels:
+            out.append((labels[m.group(1)], i))
+    return out
+
+
+def mix(body, lo, hi):
+    c = collections.Counter()
+    for l in body[lo:hi + 1]:
+        l = l.split(";")[0].strip()
+        if not l or l.endswith(":") or l.startswith("."):
+            continue
+        c[re.sub(r"_(e32|e64|sdwa|dpp)$", "", l.split()[0])] += 1
+    return c
+
+
+KERNEL_OF_WORKLOAD = {  # bench.py workload -> mangled-name fragment of its flow kernel (split3, Jacobian)
+    "disk_1Mi_T8": "flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E",
+    "disk_1Mi_T4": "flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E",
+    "spherical_16Mi_T8": "flow_kernelILi1ELi2ELi2ELb1ELi4ELb0E",
+}
+
+
+def profile(out_path):
+    """Compile the shipped kernel source to assembly and write the per-workload models bench.py reads
+    (profiles/isa_mix_latest.json)."""
+    import os
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "bsdfd.s")
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-value",
+                        "-Wno-pass-failed", "-Wno-unused-command-line-argument", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "bsdf_diffusion_sampling_amd", "csrc", "bsdfd.hip"), "-o", asm], check=True)
+        res = {w: model(asm, k) for w, k in KERNEL_OF_WORKLOAD.items()}
+    json.dump(res, open(out_path, "w"), indent=1)
+    print(f"wrote {out_path}")
+
+
+def main():
+    if sys.argv[1] == "--profile":
+        return profile(sys.argv[2])
+    print(json.dumps(model(sys.argv[1], sys.argv[2]), indent=1))
+
+
+def model(path, key):
+    lines = open(path).read().splitlines()
+    body = kernel_body(lines, key)
+    # the Euler-step loop = the SHORTEST loop that holds at least half of the MFMAs of the MFMA-richest loop
+    # (the tile loop around it holds the prologue's MFMAs as well)
+    cand = []
+    for lo, hi in loops(body):
+        c = mix(body, lo, hi)
+        cand.append((sum(v for k, v in c.items() if k.startswith("v_mfma")), hi - lo, (lo, hi)))
+    top = max(n for n, _, _ in cand)
+    best = min((span, rng) for n, span, rng in cand if 2 * n >= top)[1]
+    c = mix(body, *best)
+    mfma = {k: v for k, v in c.items() if k.startswith("v_mfma")}
+    valu = {k: v for k, v in c.items() if k.startswith("v_") and not k.startswith("v_mfma")}
+    other = {k: v for k, v in c.items() if not k.startswith("v_")}
+    meta = {}
+    # metadata block of this kernel
+    for i, l in enumerate(lines):
+        if ".name:" in l and key in l:
+            for l2 in lines[i:i + 16]:
+                for f in ("vgpr_count", "sgpr_count", "vgpr_spill_count", "private_segment_fixed_size"):
+                    m = re.search(rf"\.{f}:\s+(\d+)", l2)
+                    if m:
+                        meta[f] = int(m.group(1))
+            break
+    res = {
+        "kernel": key, "loop_lines": best[1] - best[0] + 1,
+        "mfma": mfma, "n_mfma": sum(mfma.values()),
+        "n_valu": sum(valu.values()),
+        "valu_top": dict(sorted(valu.items(), key=lambda kv: -kv[1])[:14]),
+        "n_pk_f32": sum(v for k, v in valu.items() if k.startswith("v_pk_") and k.endswith("_f32")),
+        "n_trans": sum(v for k, v in valu.items() if k in ("v_exp_f32", "v_rcp_f32", "v_log_f32", "v_sqrt_f32", "v_sin_f32",
+                                                          "v_cos_f32", "v_rsq_f32", "v_exp_f16", "v_rcp_f16")),
+        "other": other,
+        "issue_cycles_mfma": round(sum(cost(k) * v for k, v in mfma.items()), 1),
+        "issue_cycles_valu": round(sum(cost(k) * v for k, v in valu.items()), 1),
+        "meta": meta,
+    }
+    res["issue_cycles_total"] = round(res["issue_cycles_mfma"] + res["issue_cycles_valu"], 1)
+    return res
+
+
+if __name__ == "__main__":
+    main()
