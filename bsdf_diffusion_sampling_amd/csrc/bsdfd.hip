@@ -42,6 +42,12 @@
 #ifndef BSDFD_ABL
 #define BSDFD_ABL 0  // ablation bitmask for timing experiments under tools/ (always 0 in the product)
 #endif
+#ifndef BSDFD_RELOAD_LO
+#define BSDFD_RELOAD_LO 0  // experiment: bitmask of hidden-hidden layers whose W_lo fragments are re-read from LDS every step
+#endif
+#ifndef BSDFD_RELOAD_HI
+#define BSDFD_RELOAD_HI 0  // same for the W_hi fragments
+#endif
 #ifndef BSDFD_EXP
 #define BSDFD_EXP 0  // experiment bitmask for the A/B builds of tools/ab_run.sh
 #endif
@@ -176,6 +182,18 @@ __device__ __forceinline__ void sincos_enc(float a, float& s, float& c) {
 #endif
 }
 
+// LDS reads the compiler does not schedule or wait for (run-time-depth 64-wide kernels): hipcc places a layer's
+// ds_read_b128 right in front of its MFMAs and waits — with 2 waves/SIMD the ~120-cycle LDS latency is exposed twice
+// per layer.  These are issued BEFORE the layer's activation math (several hundred VALU cycles) and waited for just
+// before the first MFMA that consumes them; the wait statement names every destination as "+v", which orders all
+// consumers behind it (cdna_hip_programming.md §5.7, form (ii)).
+__device__ __forceinline__ void lds_read_b128_async(f16x8& dst, const char* p) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"((unsigned)(uintptr_t)p) : "memory");
+}
+__device__ __forceinline__ void lds_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+}
+
 union Frag {  // one MFMA B fragment: the lane's 8 K-values of a chunk
     f16x8 v;
     f16x2 p[4];
@@ -278,7 +296,10 @@ __device__ __forceinline__ float von_mises_sample(float mu, float kappa, unsigne
 //   FUSED  : compiled with the two-phase OP_SAMPLE_PDF loop (its own instantiation: the loop costs the
 //            single-op kernels 2-4 % when compiled into them)
 template <int DOMAIN, int NM, int PREC, bool JAC, int NH, bool FUSED>
-__global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_kernel(const KParams p) {
+#ifndef BSDFD_WAVES32
+#define BSDFD_WAVES32 3  // waves per SIMD the 32-wide kernels are register-allocated for
+#endif
+__global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) void flow_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // this workgroup's share of the work: the whole batch, or one material's bucket
     const char* img = p.img;
@@ -553,6 +574,12 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                 alpha = (float)(reverse ? 1.0 - tf : tf);
             }
             f32x4 z[NM], zt0[NM], zt1[NM];
+            // an opaque zero: added to the LDS address of the weight fragments that should be RE-READ every step instead
+            // of being hoisted out of the loop into registers (the compiler cannot prove the address loop-invariant)
+            int opaque0 = 0;
+#if (BSDFD_EXP & 32)
+            asm volatile("" : "+v"(opaque0));
+#endif
             if (DOMAIN == BSDFD_DOMAIN_DISK) {
                 const float bs = sel4(g, x0, x1, alpha, 0.0f);
 #pragma unroll
@@ -646,6 +673,24 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                 for (int layer = 0; layer < n_hidden; ++layer) {
                     const bool last = (layer == n_hidden - 1);
                     Frag bh[KC], bl[KC], b0h[KC], b0l[KC], b1h[KC], b1l[KC];
+                    // weight fragments of this layer: loaded asynchronously ahead of the activation math (ASYNC_W), or
+                    // by plain loads inside the K loop
+                    // (only the split3 + Jacobian 64-wide kernel: it runs 2 waves/SIMD at 225+ VGPRs; the fp16 teacher kernel
+                    // has 4 waves/SIMD to hide the latency and would lose that occupancy to the extra live registers)
+                    constexpr bool ASYNC_W = (NH == 0) && (NM == 4) && SPLIT && JAC && ((BSDFD_EXP & 64) != 0);
+                    constexpr int PRE_KC = 1;  // K chunks requested before the activation math; the next one flies behind the MFMAs
+                    f16x8 wfh[KC][NM], wfl[KC][NM];
+                    const size_t lbase = (size_t)layer * NM * KC * 64 * 16;
+                    if (ASYNC_W && !last) {
+#pragma unroll
+                        for (int kc = 0; kc < PRE_KC; ++kc)
+#pragma unroll
+                            for (int mo = 0; mo < NM; ++mo) {
+                                const size_t off = lbase + ((size_t)(mo * KC + kc) * 64 + lane) * 16;
+                                lds_read_b128_async(wfh[kc][mo], Lwh + off);
+                                if (SPLIT) lds_read_b128_async(wfl[kc][mo], Lwh_lo + off);
+                            }
+                    }
 #pragma unroll
                     for (int m = 0; m < NM; ++m) {
                         float hv[4], t0v[4], t1v[4];
@@ -666,7 +711,6 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                         }
                     }
                     if (!last) {
-                        const size_t lbase = (size_t)layer * NM * KC * 64 * 16;
                         f32x4 a[NM], a0[NM], a1[NM];
 #pragma unroll
                         for (int mo = 0; mo < NM; ++mo) { a[mo] = zero4; a0[mo] = zero4; a1[mo] = zero4; }
@@ -676,11 +720,30 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 #pragma unroll
                         for (int kc = 0; kc < KC; ++kc) {
                             f16x8 wh[NM], wl[NM];
+                            if (ASYNC_W) {
+                                if (NM == 4) {  // (the helper is written for 4 fragments)
+                                    lds_wait4(wfh[kc][0], wfh[kc][1], wfh[kc][2 % NM], wfh[kc][3 % NM]);
+                                    if (SPLIT) lds_wait4(wfl[kc][0], wfl[kc][1], wfl[kc][2 % NM], wfl[kc][3 % NM]);
+                                }
+                                if (kc + 1 < KC && kc + 1 >= PRE_KC) {  // next chunk: in flight behind this chunk's MFMAs
 #pragma unroll
-                            for (int mo = 0; mo < NM; ++mo) {
-                                const size_t off = lbase + ((size_t)(mo * KC + kc) * 64 + lane) * 16;
-                                wh[mo] = *reinterpret_cast<const f16x8*>(Lwh + off);
-                                if (SPLIT) wl[mo] = *reinterpret_cast<const f16x8*>(Lwh_lo + off);
+                                    for (int mo = 0; mo < NM; ++mo) {
+                                        const size_t off = lbase + ((size_t)(mo * KC + kc + 1) * 64 + lane) * 16;
+                                        lds_read_b128_async(wfh[(kc + 1) % KC][mo], Lwh + off);
+                                        if (SPLIT) lds_read_b128_async(wfl[(kc + 1) % KC][mo], Lwh_lo + off);
+                                    }
+                                }
+#pragma unroll
+                                for (int mo = 0; mo < NM; ++mo) { wh[mo] = wfh[kc][mo]; if (SPLIT) wl[mo] = wfl[kc][mo]; }
+                            } else {
+#pragma unroll
+                                for (int mo = 0; mo < NM; ++mo) {
+                                    const size_t off = lbase + ((size_t)(mo * KC + kc) * 64 + lane) * 16;
+                                    const bool re_hi = NH > 0 && DOMAIN == BSDFD_DOMAIN_SPHERICAL && ((BSDFD_RELOAD_HI >> layer) & 1);
+                                    const bool re_lo = NH > 0 && DOMAIN == BSDFD_DOMAIN_SPHERICAL && ((BSDFD_RELOAD_LO >> layer) & 1);
+                                    wh[mo] = *reinterpret_cast<const f16x8*>(Lwh + off + (re_hi ? opaque0 : 0));
+                                    if (SPLIT) wl[mo] = *reinterpret_cast<const f16x8*>(Lwh_lo + off + (re_lo ? opaque0 : 0));
+                                }
                             }
 #pragma unroll
                             for (int mo = 0; mo < NM; ++mo) {

@@ -5,7 +5,7 @@
 // clock the chip sustains UNDER A SIMILAR LOAD (an MI355X runs this instruction mix at ~2.0-2.2 GHz, not at
 // the 2.4 GHz maximum: MI355X_MICROARCH.md "DVFS give-back").  The probe fills every CU with waves that
 // issue the flow kernel's per-layer mix (fp16 MFMAs + fp32 VALU + transcendentals) for a few milliseconds and
-// divides the shader-cycle counter (s_memtime) delta of one wave by the HIP-event duration of the launch.
+// divides the largest shader-cycle counter (s_memtime) delta over all waves by the HIP-event duration of the launch.
 #include <hip/hip_runtime.h>
 
 #include "bsdfd.h"
@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256, 3) void clock_probe_kernel(int iters, unsigned
     for (int j = 0; j < 8; ++j) acc += a[j];
     for (int j = 0; j < 6; ++j) acc += c[j][0] + c[j][3];
     if (acc == 12345.678f) sink[0] = acc;  // keeps the loop alive
-    if (blockIdx.x == 0 && threadIdx.x == 0) *cycles = (unsigned long long)(t1 - t0);
+    // the LONGEST-lived wave spans the launch: the oldest wave of a SIMD is favoured by the issue arbiter and finishes its
+    // iterations in under half of the kernel's duration (wave 0 alone under-reported the clock 2.3x)
+    if ((threadIdx.x & 63) == 0) atomicMax(cycles, (unsigned long long)(t1 - t0));
 }
 
 }  // namespace
@@ -69,7 +71,8 @@ extern "C" int bsdfd_shader_clock_mhz(double* mhz, void* hip_stream) {
     // two launches: the first also absorbs the clock ramp after an idle period
     for (int rep = 0; rep < 2 && rc == BSDFD_OK; ++rep) {
         const int iters = rep == 0 ? 2000 : 6000;  // ~1.5 ms and ~4.5 ms
-        hipError_t e = hipEventRecord(e0, s);
+        hipError_t e = hipMemsetAsync(d_cyc, 0, sizeof(unsigned long long), s);
+        if (e == hipSuccess) e = hipEventRecord(e0, s);
         if (e == hipSuccess) {
             clock_probe_kernel<<<grid, 256, 0, s>>>(iters, d_cyc, d_sink);
             e = hipGetLastError();

@@ -21,8 +21,30 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _i64(v: int) -> int:
+    """uint64 seed / offset -> the int64 the operator schema carries (same 64 bits)."""
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def default_binding() -> str:
+    """'torch' (the operator library torch.ops.bsdfd.*, csrc/torch_ops.cpp) when it has been built, else 'ctypes';
+    $BSDFD_HOST_BINDING overrides.  Both are host shims over the same C ABI and the same kernels."""
+    import os
+    from . import torch_ext
+    b = os.environ.get("BSDFD_HOST_BINDING")
+    if b:
+        if b not in ("ctypes", "torch"):
+            raise RuntimeError(f"BSDFD_HOST_BINDING must be 'ctypes' or 'torch', got {b!r}")
+        return b
+    return "torch" if torch_ext.available() else "ctypes"
+
+
 class FlowSampler:
-    def __init__(self, fw: "W.FlowWeights | str", precision: str = "default", device: Optional[int] = None):
+    def __init__(self, fw: "W.FlowWeights | str", precision: str = "default", device: Optional[int] = None,
+                 binding: Optional[str] = None):
+        """``binding``: 'ctypes' or 'torch' — which host shim the per-call entry points go through (default:
+        ``default_binding()``).  The handle is created through the C ABI either way and is the same object."""
         if not torch.cuda.is_available():
             raise RuntimeError("FlowSampler needs an MI355X (torch.cuda is unavailable); there is no CPU path")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
@@ -45,6 +67,14 @@ class FlowSampler:
             _lib.check(L.bsdfd_create(C.byref(d), C.byref(h)))
         self._h = h
         self._L = L
+        self.binding = binding or default_binding()
+        if self.binding not in ("ctypes", "torch"):
+            raise RuntimeError(f"binding must be 'ctypes' or 'torch', got {self.binding!r}")
+        self._ops = None
+        if self.binding == "torch":
+            from . import torch_ext
+            self._ops = torch_ext.load()
+            self._hi = int(h.value)
         p = C.c_int32()
         _lib.check(L.bsdfd_get_info(h, None, None, None, C.byref(p)))
         self.precision = {v: k for k, v in _lib.PRECISIONS.items()}[p.value]
@@ -78,6 +108,12 @@ class FlowSampler:
             raise RuntimeError(f"{name} must be contiguous")
         return t
 
+    def _dev_chk(self, t, name: str):
+        """torch binding: dtype / shape / contiguity are checked in C++ (csrc/torch_ops.cpp); the one thing the
+        operator cannot know is which device the HANDLE lives on."""
+        if not isinstance(t, torch.Tensor) or t.device != self.device:
+            raise RuntimeError(f"{name} must be a tensor on {self.device} (the sampler's device)")
+
     def _chk1(self, t: torch.Tensor, n: int, name: str):
         """A caller-supplied 1-D output (pdf [N]): the kernel writes N floats through its raw pointer."""
         if not isinstance(t, torch.Tensor) or not t.is_cuda or t.device != self.device:
@@ -107,6 +143,9 @@ class FlowSampler:
     # ---- operator level (rendering/utils/mlp_brdf_sampling.py) -------
     def network_sampling(self, omega_i, x0=None, T: int = 4, seed: int = 0, offset: int = 0
                          ) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._ops is not None:
+            self._dev_chk(omega_i, "omega_i")
+            return self._ops.network_sampling(self._hi, omega_i, x0, _i64(seed), _i64(offset), T)
         omega_i = self._chk(omega_i, 2, "omega_i")
         n = omega_i.shape[0]
         x0 = self._chk(x0, 2, "x0", n)
@@ -118,6 +157,9 @@ class FlowSampler:
         return x, pdf
 
     def network_pdf(self, omega_o, omega_i, T: int = 4) -> torch.Tensor:
+        if self._ops is not None:
+            self._dev_chk(omega_i, "omega_i")
+            return self._ops.network_pdf(self._hi, omega_o, omega_i, T)
         omega_i = self._chk(omega_i, 2, "omega_i")
         n = omega_i.shape[0]
         omega_o = self._chk(omega_o, 2, "omega_o", n)
@@ -128,6 +170,9 @@ class FlowSampler:
         return pdf
 
     def flow_samples_only(self, omega_i, x0, T: int) -> torch.Tensor:
+        if self._ops is not None:
+            self._dev_chk(omega_i, "omega_i")
+            return self._ops.flow_samples_only(self._hi, omega_i, x0, T)
         omega_i = self._chk(omega_i, 2, "omega_i")
         n = omega_i.shape[0]
         x0 = self._chk(x0, 2, "x0", n)
@@ -140,6 +185,12 @@ class FlowSampler:
     # ---- plugin level (tensor core of MyBSDF.sample / MyBSDF.pdf) ----
     def plugin_sample(self, wi, x0=None, T: int = 4, variant: int = _lib.PLUGIN_MEASURED, seed: int = 0,
                       offset: int = 0, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        if self._ops is not None:
+            self._dev_chk(wi, "wi")
+            if out is None:
+                return self._ops.plugin_sample(self._hi, variant, wi, x0, _i64(seed), _i64(offset), T)
+            self._ops.plugin_sample_out(self._hi, variant, wi, x0, _i64(seed), _i64(offset), T, out[0], out[1])
+            return out[0], out[1]
         wi = self._chk(wi, 3, "wi")
         n = wi.shape[0]
         x0 = self._chk(x0, 2, "x0", n)
@@ -157,6 +208,9 @@ class FlowSampler:
                           offset: int = 0, out: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None):
         """sample(wi) and pdf(wi, wl) of the same intersections in ONE launch (the per-query prologue is
         shared): -> (wo [N,3], pdf(wo) [N], pdf(wl) [N]), identical to plugin_sample + plugin_pdf(wi, wl)."""
+        if self._ops is not None and out is None:
+            self._dev_chk(wi, "wi")
+            return self._ops.plugin_sample_pdf(self._hi, variant, wi, wl, x0, _i64(seed), _i64(offset), T)
         wi = self._chk(wi, 3, "wi")
         n = wi.shape[0]
         wl = self._chk(wl, 3, "wl", n)
@@ -175,6 +229,12 @@ class FlowSampler:
 
     def plugin_pdf(self, wi, wo, T: int = 4, variant: int = _lib.PLUGIN_MEASURED,
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self._ops is not None:
+            self._dev_chk(wi, "wi")
+            if out is None:
+                return self._ops.plugin_pdf(self._hi, variant, wi, wo, T)
+            self._ops.plugin_pdf_out(self._hi, variant, wi, wo, T, out)
+            return out
         wi = self._chk(wi, 3, "wi")
         n = wi.shape[0]
         wo = self._chk(wo, 3, "wo", n)

@@ -47,4 +47,7 @@ def _built_library():
     from bsdf_diffusion_sampling_amd import _lib
     if shutil.which("hipcc"):
         _lib.build()
+        if shutil.which("g++"):
+            from bsdf_diffusion_sampling_amd import torch_ext
+            torch_ext.build()
     yield

@@ -48,7 +48,9 @@ def test_bench_line_single_gpu_with_secondary_and_cpu_baseline():
     ib = d["roofline"]["issue_bound"]
     assert 1000 < ib["shader_clock_mhz"] < 2500 and 0.5 < ib["frac_of_issue_bound"] < 1.3, ib
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["value"] > 0 and cb["all_cores"]["value"] > 0 and cb["all_cores"]["cores"] >= cb["cores"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["all_cores"]["cores"] >= cb["cores"]
+    ac = cb["all_cores"]  # a child process with a time budget: a figure, or an honest "did not finish" with an upper bound
+    assert (ac["value"] is not None and ac["value"] > 0) or (ac["timed_passes_finished"] == 0 and ac["value_upper_bound"] > 0)
     for name in ("disk_1Mi_T4", "spherical_16Mi_T8", "mixed_16Mi", "teacher_64x6_4Mi_T128"):
         s = d["secondary"][name]
         assert "error" not in s, s

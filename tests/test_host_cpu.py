@@ -313,3 +313,20 @@ def test_bench_self_launch_fails_loudly_without_gpus():
                         "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_torch_operator_library_registers_every_operator():
+    """libbsdfd_torch.so (csrc/torch_ops.cpp) loads without a GPU and registers torch.ops.bsdfd.* — one operator per
+    C-ABI entry point of the hot path; compute calls need the GPU and fail loudly without one."""
+    import torch
+    from bsdf_diffusion_sampling_amd import torch_ext
+    ns = torch_ext.load()
+    for name in torch_ext.OPS:
+        assert hasattr(ns, name), name
+    schema = torch.ops.bsdfd.plugin_sample.default._schema
+    assert [a.name for a in schema.arguments] == ["handle", "variant", "wi", "x0", "seed", "offset", "T"]
+    with pytest.raises(RuntimeError):
+        ns.plugin_pdf(0, 0, torch.zeros(4, 3), torch.zeros(4, 3), 4)      # CPU tensors / null handle: refused
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            ns.create_from_file("/nonexistent.bsdfw", 0, 0)

@@ -139,3 +139,19 @@ def test_plugin_guards_disk_and_spherical():
     wo3, pdf = O.plugin_sample_spherical(orc, wi3, g["x0"], T=8)
     assert np.allclose((wo3 ** 2).sum(1), 1.0)
     assert np.all(pdf[wo3[:, 2] <= 0] == 0)
+
+
+@pytest.mark.parametrize("T", [128, 256])
+def test_disk_reflow_teacher_matches_reference(T):
+    """SURVEY §8 f2, disk teacher (learning_repo_cleanup/disk_domain_sampling.py:93-110: 32 x 3 diffusion net, T = 128 /
+    the script's default 256 Euler steps, no Jacobian): the oracle's samples-only flow vs the reference's own
+    `NN_cond_pos_simpler` stepped by tests/golden/make_teacher_golden.py — fp64 to round-off, fp32 to its noise."""
+    import os
+    from conftest import GOLDEN
+    from bsdf_diffusion_sampling_amd import weights as W
+    g = np.load(os.path.join(GOLDEN, "disk_teacher_aniso_miro_7_rgb.npz"))
+    fw = W.load(W.shipped_path("aniso_miro_7_rgb", "disk", "diffusion"))
+    assert (fw.width, fw.n_hidden) == (32, 3)
+    x, _ = O.Oracle(fw).flow(g["x0"], g["wi"], T, reverse=False)
+    assert np.abs(x - g[f"x_T{T}_f64"]).max() < 1e-10
+    assert np.abs(x - g[f"x_T{T}_f32"]).max() < 5e-5

@@ -33,8 +33,13 @@ def main():
     ap.add_argument("--out", default=W.DATA_DIR)
     ap.add_argument("--complex", default="aniso_miro_7_rgb,chm_orange_rgb,bsdf_3",
                     help="comma list of materials whose 64-wide teacher net is exported too")
+    ap.add_argument("--diffusion", default="aniso_miro_7_rgb",
+                    help="comma list of materials whose DISK reflow teacher (brdf_diffusion_network*, 32 x 3: "
+                         "learning_repo_cleanup/disk_domain_sampling.py:73-75) is exported too, as <mat>_disk_diffusion.bsdfw")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
+    want_diffusion = set(filter(None, a.diffusion.split(",")))
+    n_diff = 0
     n = 0
     n_complex = 0
     want_complex = set(filter(None, a.complex.split(",")))
@@ -58,12 +63,16 @@ def main():
         fw = W.from_state_dicts(mat, domain, _load(rect), base_sd)
         W.save(os.path.join(a.out, f"{mat}_{dom}.bsdfw"), fw)
         n += 1
+        dif = os.path.join(full, f"brdf_diffusion_network{tag}.pth")
+        if dom == "disk" and os.path.exists(dif) and mat in want_diffusion:
+            W.save(os.path.join(a.out, f"{mat}_{dom}_diffusion.bsdfw"), W.from_state_dicts(mat, domain, _load(dif), base_sd))
+            n_diff += 1
         cpx = os.path.join(full, f"brdf_diffusion_network_complex{tag}.pth")
         if dom == "spherical" and os.path.exists(cpx) and mat in want_complex:
             fwc = W.from_state_dicts(mat, domain, _load(cpx), base_sd)
             W.save(os.path.join(a.out, f"{mat}_{dom}_complex.bsdfw"), fwc)
             n_complex += 1
-    print(f"wrote {n} weight sets (+{n_complex} complex) to {a.out}")
+    print(f"wrote {n} weight sets (+{n_complex} complex, +{n_diff} disk teachers) to {a.out}")
 
 
 if __name__ == "__main__":

@@ -7,8 +7,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline $*"
-TRACE_ARGS="--no-cpu-baseline $*"   # the default bench.py run (50 steps / 5 warm-up): same command as the judged line
+ARGS="--steps 10 --warmup 2 --passes-per-step 1 --no-cpu-baseline --no-secondary $*"
+TRACE_ARGS="--no-cpu-baseline --no-secondary $*"   # the default bench.py run (50 steps / 5 warm-up, step sized to >= 0.5 s): the judged line's timed region
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $REPO/bench.py $TRACE_ARGS > $OUT/trace.log 2>&1
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS" \

@@ -41,6 +41,16 @@ def main():
     # the stats average covers EVERY launch of the command (clock-settle phase, warm-up, timed region, per-kind
     # split); the per-launch trace lets us average exactly the timed region's launches as bench.py's events do
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else 50
+    # the traced command's own JSON line says how many wavefronts a step was sized to (>= 0.5 s timed region)
+    try:
+        line = [l for l in open(os.path.join(src, "trace.log")) if l.startswith("{")][-1]
+        bench = json.loads(line)
+        steps = bench["steps"] * bench["config"].get("passes_per_step", 1)
+        out["bench_line"] = {k: bench[k] for k in ("value", "ms_per_step", "steps") if k in bench}
+        out["bench_line"]["roofline"] = {k: bench["roofline"].get(k) for k in ("avg_launch_ms", "frac", "launches")}
+        out["bench_line"]["passes_per_step"] = bench["config"].get("passes_per_step", 1)
+    except Exception:
+        pass
     tr = glob.glob(os.path.join(src, "trace", "trace_kernel_trace.csv"))
     if tr and "kernel_trace" in out:
         rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr[0]))
