@@ -36,8 +36,14 @@ def _packed(D_base, D_sample, domain: int, precision: str) -> FlowSampler:
             raise RuntimeError("FlowSampler domain does not match the operator called")
         return D_sample
     from . import model as M
-    key = (id(D_base), getattr(D_base, "_bsdfd_version", 0), getattr(D_sample, "_bsdfd_version", 0), domain,
-           precision, torch.cuda.current_device())
+    # The packed device handle is cached on D_sample, keyed by the IDENTITY AND VERSION of every weight tensor of
+    # the pair: (data_ptr, torch's in-place version counter) per state-dict entry.  An optimiser step, a
+    # load_state_dict or any other in-place update of a real reference nn.Module bumps `_version` (and a rebind
+    # changes data_ptr), so a training loop that samples from a net it is updating (the reflow stage) never sees
+    # stale packed weights; a frozen net costs one tuple of ~10 integers per call.
+    def stamp(mod):
+        return tuple((k, v.data_ptr(), v._version) for k, v in mod.state_dict(keep_vars=True).items())
+    key = (stamp(D_base), stamp(D_sample), domain, precision, torch.cuda.current_device())
     cache = D_sample.__dict__.setdefault("_bsdfd_cache", {})
     s = cache.get(key)
     if s is None:
@@ -45,6 +51,13 @@ def _packed(D_base, D_sample, domain: int, precision: str) -> FlowSampler:
         s = FlowSampler(M.to_flow_weights(D_base, D_sample, domain), precision=precision)
         cache[key] = s
     return s
+
+
+def repack(D_sample) -> None:
+    """Drop the cached device handle of ``D_sample`` (next call re-packs).  Only needed after writes torch's
+    version counter cannot see, i.e. through ``param.data`` (``p.data.mul_(...)``); optimiser steps,
+    ``load_state_dict`` and ``with torch.no_grad(): p.copy_/add_(...)`` are detected automatically."""
+    D_sample.__dict__.pop("_bsdfd_cache", None)
 
 
 def _seed(seed: Optional[int]) -> int:

@@ -70,5 +70,9 @@ def test_bench_self_launches_two_ranks(workload):
     assert mg["judged"] == "final" and abs(mg["Msamples_per_s_final_gather"] - two["value"]) < 1e-9 * two["value"] + 1e-9
     assert mg["Msamples_per_s_no_gather"] > 0 and mg["Msamples_per_s_gather_every_step_overlapped"] > 0
     assert mg["gather_bytes_per_rank"] == two["config"]["queries_per_wavefront_per_gpu"] * 16
-    # two ranks time-share one GPU: the job-level rate cannot exceed ~1x the single-rank rate (and is not far below it)
-    assert 0.3 * one["value"] < two["value"] < 1.3 * one["value"], (one["value"], two["value"])
+    # two ranks time-share one GPU: without the gather the job-level rate is ~1x the single-rank rate; the judged rate
+    # (one gather of the final shards, here staged through HOST memory by gloo inside a deliberately tiny timed region)
+    # can only be lower
+    ng = mg["Msamples_per_s_no_gather"]
+    assert 0.3 * one["value"] < ng < 1.3 * one["value"], (one["value"], ng)
+    assert two["value"] <= 1.05 * ng

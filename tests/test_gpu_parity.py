@@ -405,6 +405,37 @@ def test_disk_reflow_teacher_sampler_long_T(T):
     assert np.array_equal(x_part, xs3[:333])
 
 
+def test_operator_functions_repack_after_in_place_weight_updates():
+    """The four operator functions cache the packed device handle on D_sample; the cache key carries data_ptr and
+    torch's version counter of every weight, so an optimiser-style in-place update (the reflow training loop samples
+    from the net it is updating, learning_repo_cleanup/disk_domain_sampling.py:112-140) is never served stale weights."""
+    from bsdf_diffusion_sampling_amd import mlp_brdf_sampling as ops
+    from bsdf_diffusion_sampling_amd import model as M
+    from bsdf_diffusion_sampling_amd import weights as W
+    g, fw = load_case("chm_orange_rgb_disk")
+    db, ds = M.from_flow_weights(fw)
+    wi, x0 = _t(g["wi"][:512]), _t(g["x0"][:512])
+    x_a, p_a = ops.network_sampling_disk(db, ds, wi, T=4, x0=x0)
+    s_a = ds.__dict__["_bsdfd_cache"]
+    x_b, _ = ops.network_sampling_disk(db, ds, wi, T=4, x0=x0)
+    assert torch.equal(x_a, x_b) and ds.__dict__["_bsdfd_cache"] is s_a and len(s_a) == 1   # cached: no re-pack
+    with torch.no_grad():
+        ds.output.weight.mul_(0.5)                                                           # what an optimiser step does
+    x_c, _ = ops.network_sampling_disk(db, ds, wi, T=4, x0=x0)
+    fw2 = M.to_flow_weights(db, ds, W.DOMAIN_DISK)
+    xo, _ = O.Oracle(fw2).network_sampling(g["wi"][:512], g["x0"][:512], 4)
+    assert not torch.equal(x_a, x_c) and np.abs(x_c.cpu().numpy() - xo).max() < 1e-4
+    with torch.no_grad():
+        db.output.bias.add_(0.01)                                                            # the base net counts too
+    _, p_d = ops.network_sampling_disk(db, ds, wi, T=4, x0=x0)
+    _, p_c = ops.network_sampling_disk(db, ds, wi, T=4, x0=x0)
+    assert torch.equal(p_c, p_d)
+    ds.output.weight.data.mul_(2.0)                                                          # invisible to the counter ...
+    ops.repack(ds)                                                                           # ... hence the explicit hook
+    x_e, _ = ops.network_sampling_disk(db, ds, wi, T=4, x0=x0)
+    assert torch.allclose(x_e, x_a, atol=1e-6)
+
+
 def test_extreme_inputs_do_not_crash_and_fail_loudly():
     """Absurd states (|x0| = 1e4 .. 1e30, NaN): the fp32 reference overflows its own exp()/products; the
     split-fp16 path additionally leaves fp16 range.  Required: no fault, the neighbouring queries of the
