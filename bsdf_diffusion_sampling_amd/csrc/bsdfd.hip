@@ -75,7 +75,7 @@ constexpr int MAX_SEG = 64;  // materials per segmented launch (the descriptors 
 enum { IO_OPERATOR = 0, IO_PLUGIN = 1, IO_PLUGIN_FULLSPHERE = 2 };
 
 struct ImgLayout {  // byte offsets into the weight image (identical in global memory and LDS)
-    int win, wc, wh, wh_lo, wo, bw1, bb1, bw2, bb2, total;
+    int win, wc, wh, wh_lo, wo, wo32, bw1, bb1, bw2, bb2, total;
 };
 
 struct KParams {
@@ -343,6 +343,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
     const char* Lwh = smem + p.L.wh;
     const char* Lwh_lo = smem + p.L.wh_lo;
     const char* Lwo = smem + p.L.wo;
+    const float* Lwo32 = reinterpret_cast<const float*>(smem + p.L.wo32);
     const float* Lbw1 = reinterpret_cast<const float*>(smem + p.L.bw1);
     const float* Lbb1 = reinterpret_cast<const float*>(smem + p.L.bb1);
     const float* Lbw2 = reinterpret_cast<const float*>(smem + p.L.bw2);
@@ -673,6 +674,12 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
                 for (int layer = 0; layer < n_hidden; ++layer) {
                     const bool last = (layer == n_hidden - 1);
                     Frag bh[KC], bl[KC], b0h[KC], b0l[KC], b1h[KC], b1l[KC];
+                    // OUT_VALU: the 2-row output layer as fp32 dot products on the VALU.  The last hidden layer's
+                    // activations and tangents then need no hi/lo split (3 x 8 values per lane: 9 VALU each) and the six
+                    // 14/16-empty output MFMAs go away; the price is 8 FMAs per unit and an all-reduce of six partial sums
+                    // over the 4 lanes of a query.
+                    constexpr bool OUT_VALU = (BSDFD_EXP & 128) != 0;
+                    float pv0 = 0.f, pv1 = 0.f, p00 = 0.f, p01 = 0.f, p10 = 0.f, p11 = 0.f;
                     // weight fragments of this layer: loaded asynchronously ahead of the activation math (ASYNC_W), or
                     // by plain loads inside the K loop
                     // (only the split3 + Jacobian 64-wide kernel: it runs 2 waves/SIMD at 225+ VGPRs; the fp16 teacher kernel
@@ -704,6 +711,20 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
                             }
                         }
                         const int kc = m >> 1, q0 = 2 * (m & 1);
+                        if (OUT_VALU && last) {
+                            const f32x4 w0 = *reinterpret_cast<const f32x4*>(Lwo32 + ((m * 64 + lane) * 2 + 0) * 4);
+                            const f32x4 w1 = *reinterpret_cast<const f32x4*>(Lwo32 + ((m * 64 + lane) * 2 + 1) * 4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                pv0 = fmaf(w0[r], hv[r], pv0);
+                                pv1 = fmaf(w1[r], hv[r], pv1);
+                                if (JAC) {
+                                    p00 = fmaf(w0[r], t0v[r], p00); p01 = fmaf(w0[r], t1v[r], p01);
+                                    p10 = fmaf(w1[r], t0v[r], p10); p11 = fmaf(w1[r], t1v[r], p11);
+                                }
+                            }
+                            continue;
+                        }
                         split_pack<SPLIT>(hv, bh[kc].p[q0], bh[kc].p[q0 + 1], bl[kc].p[q0], bl[kc].p[q0 + 1]);
                         if (JAC) {
                             split_pack<TSPLIT>(t0v, b0h[kc].p[q0], b0h[kc].p[q0 + 1], b0l[kc].p[q0], b0l[kc].p[q0 + 1]);
@@ -772,6 +793,20 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
 #endif
 #pragma unroll
                         for (int mo = 0; mo < NM; ++mo) { z[mo] = a[mo]; zt0[mo] = a0[mo]; zt1[mo] = a1[mo]; }
+                    } else if (OUT_VALU) {
+                        // all-reduce over the query's 4 lanes (lane ^ 16, lane ^ 32); every lane ends up with the totals,
+                        // so the state update and the determinant below stay lane-local (the weights carry the -ln 2
+                        // of the scaled-activation convention, build_image).
+                        auto allred = [](float x) {
+                            x += __shfl_xor(x, 16, 64);
+                            x += __shfl_xor(x, 32, 64);
+                            return x;
+                        };
+                        v[0] = allred(pv0); v[1] = allred(pv1);
+                        if (JAC) {
+                            d0[0] = allred(p00); d0[1] = allred(p10);
+                            d1[0] = allred(p01); d1[1] = allred(p11);
+                        }
                     } else {
                         // output layer: A rows (i&3) = {Wout_hi[0], Wout_hi[1], Wout_lo[0], Wout_lo[1]}, so
                         // e[0..1] = hi*hi + hi*lo and e[2..3] = lo*hi (+ lo*lo, ~2^-22): out = e[o] + e[o+2]
@@ -941,6 +976,7 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
         if (prec == BSDFD_PREC_SPLIT3) off += (NH - 1) * NM * KC * 64 * 16;
         L.wo = off; off += KC * 64 * 16;
     }
+    L.wo32 = off; off += NM * 64 * 8 * 4;  // fp32 output-layer weights per lane-unit: [m][lane][o][r]
     L.bw1 = off; off += (BASE_PE_BANDS + 1) * 64 * 4;
     L.bb1 = off; off += 64 * 16;
     L.bw2 = off; off += 64 * 16;
@@ -971,6 +1007,11 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
         }
     }
     for (int r = 0; r < 4; ++r) F(L.bb2)[r] = d.base_b2[r];
+    for (int m = 0; m < NM; ++m)
+        for (int l = 0; l < 64; ++l)
+            for (int o = 0; o < 2; ++o)
+                for (int r = 0; r < 4; ++r)
+                    F(L.wo32)[((m * 64 + l) * 2 + o) * 4 + r] = d.w_out[o * W + 16 * m + 4 * (l >> 4) + r];
 
     if (prec == BSDFD_PREC_F32) {
         for (int layer = 0; layer < NH - 1; ++layer)
