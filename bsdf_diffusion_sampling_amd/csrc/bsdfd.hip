@@ -39,18 +39,6 @@
 #include "bsdfd.h"
 #include "common.h"
 
-#ifndef BSDFD_ABL
-#define BSDFD_ABL 0  // ablation bitmask for timing experiments under tools/ (always 0 in the product)
-#endif
-#ifndef BSDFD_RELOAD_LO
-#define BSDFD_RELOAD_LO 0  // experiment: bitmask of hidden-hidden layers whose W_lo fragments are re-read from LDS every step
-#endif
-#ifndef BSDFD_RELOAD_HI
-#define BSDFD_RELOAD_HI 0  // same for the W_hi fragments
-#endif
-#ifndef BSDFD_EXP
-#define BSDFD_EXP 0  // experiment bitmask for the A/B builds of tools/ab_run.sh
-#endif
 
 namespace {
 
@@ -68,14 +56,16 @@ constexpr int PE_SLABS = PE_BANDS + 1;  // K=4 slabs: one per band (sin/cos x 2 
 // hi*hi + hi*lo + lo*hi accumulate into ONE fp32 accumulator.
 
 enum { OP_SAMPLE = 0, OP_PDF = 1, OP_SAMPLES_ONLY = 2, OP_SAMPLE_PDF = 3 };  // 3: plugin io only, sample(wi) then pdf(wi, wl)
-#ifndef BSDFD_TPREC
-#define BSDFD_TPREC 3
-#endif
+// Precision of the TANGENT contractions: 3 = hi+lo operands and the W_lo product, like the activations.  Cheaper settings
+// were measured and rejected (2: operands rounded to fp16, -29 % time, p99 pdf error 4e-4 .. 7e-3; 1: single product,
+// 7e-4 .. 8e-3 — the 2x2 determinant of a sharp lobe cancels heavily); the ablation builds live in git history
+// (commit 5a33ef0), not in the product source.
+constexpr int kTangentPrec = 3;
 constexpr int MAX_SEG = 64;  // materials per segmented launch (the descriptors travel in the kernel arguments)
 enum { IO_OPERATOR = 0, IO_PLUGIN = 1, IO_PLUGIN_FULLSPHERE = 2 };
 
 struct ImgLayout {  // byte offsets into the weight image (identical in global memory and LDS)
-    int win, wc, wh, wh_lo, wo, wo32, bw1, bb1, bw2, bb2, total;
+    int win, wc, wh, wh_lo, wo, bw1, bb1, bw2, bb2, total;
 };
 
 struct KParams {
@@ -139,16 +129,6 @@ __device__ __forceinline__ float silu(float z) {  // base net: unscaled
 // hi/lo split of an fp32 value into two fp16-representable fp32 values (see header comment)
 __device__ __forceinline__ float hi_part(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFFE000u); }
 
-__device__ __forceinline__ float sub_f32(float a, float b) {
-#if (BSDFD_EXP & 1)  // keep x - hi a plain v_sub_f32 (no SLP v_pk_add_f32, no v_fma_mix fusion with the conversion)
-    float r;
-    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#else
-    return a - b;
-#endif
-}
-
 // sin and cos of a bounded argument (|a| <~ 1e3; the encoder's arguments are 2^b y with |y| <= pi, b <= 4): Cody-Waite
 // reduction by pi/2 in four parts (8 + 11 + 11 bits + remainder: k * part is exact, so is the first subtraction) and
 // the Cephes single-precision kernels on [-pi/4, pi/4]; max abs error 9.2e-8 (numpy prototype vs fp64, 8 M
@@ -173,25 +153,12 @@ __device__ __forceinline__ void sincos_bounded(float a, float& s_out, float& c_o
     c_out = __uint_as_float(__float_as_uint(cc) ^ ((unsigned)((n + 1) & 2) << 30));
 }
 
+// The encoder's and the spherical net's sines / cosines: the bounded-argument kernel above, libm's sincosf only for
+// arguments the reference never produces.  Within-run A/B against sincosf everywhere (profiles/r02_ab/ab4): spherical
+// kernels -1.0 %, 64-wide -0.8 %, disk +-0 (noise); p99 pdf error unchanged on all seven golden sets.
 __device__ __forceinline__ void sincos_enc(float a, float& s, float& c) {
-#if (BSDFD_EXP & 8)
     if (__builtin_expect(fabsf(a) <= 1024.0f, 1)) sincos_bounded(a, s, c);
     else sincosf(a, &s, &c);
-#else
-    sincosf(a, &s, &c);
-#endif
-}
-
-// LDS reads the compiler does not schedule or wait for (run-time-depth 64-wide kernels): hipcc places a layer's
-// ds_read_b128 right in front of its MFMAs and waits — with 2 waves/SIMD the ~120-cycle LDS latency is exposed twice
-// per layer.  These are issued BEFORE the layer's activation math (several hundred VALU cycles) and waited for just
-// before the first MFMA that consumes them; the wait statement names every destination as "+v", which orders all
-// consumers behind it (cdna_hip_programming.md §5.7, form (ii)).
-__device__ __forceinline__ void lds_read_b128_async(f16x8& dst, const char* p) {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"((unsigned)(uintptr_t)p) : "memory");
-}
-__device__ __forceinline__ void lds_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
 }
 
 union Frag {  // one MFMA B fragment: the lane's 8 K-values of a chunk
@@ -204,8 +171,8 @@ __device__ __forceinline__ void split_pack(const float (&x)[4], f16x2& h01, f16x
         const float h0 = hi_part(x[0]), h1 = hi_part(x[1]), h2 = hi_part(x[2]), h3 = hi_part(x[3]);
         h01 = (f16x2){(_Float16)h0, (_Float16)h1};
         h23 = (f16x2){(_Float16)h2, (_Float16)h3};
-        l01 = (f16x2){(_Float16)sub_f32(x[0], h0), (_Float16)sub_f32(x[1], h1)};
-        l23 = (f16x2){(_Float16)sub_f32(x[2], h2), (_Float16)sub_f32(x[3], h3)};
+        l01 = (f16x2){(_Float16)(x[0] - h0), (_Float16)(x[1] - h1)};
+        l23 = (f16x2){(_Float16)(x[2] - h2), (_Float16)(x[3] - h3)};
     } else {
         h01 = (f16x2){(_Float16)x[0], (_Float16)x[1]};
         h23 = (f16x2){(_Float16)x[2], (_Float16)x[3]};
@@ -296,10 +263,7 @@ __device__ __forceinline__ float von_mises_sample(float mu, float kappa, unsigne
 //   FUSED  : compiled with the two-phase OP_SAMPLE_PDF loop (its own instantiation: the loop costs the
 //            single-op kernels 2-4 % when compiled into them)
 template <int DOMAIN, int NM, int PREC, bool JAC, int NH, bool FUSED>
-#ifndef BSDFD_WAVES32
-#define BSDFD_WAVES32 3  // waves per SIMD the 32-wide kernels are register-allocated for
-#endif
-__global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) void flow_kernel(const KParams p) {
+__global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // this workgroup's share of the work: the whole batch, or one material's bucket
     const char* img = p.img;
@@ -322,13 +286,6 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
         for (int i = threadIdx.x; i < p.L.total / 16; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
-#if (BSDFD_EXP & 4)  // static priority: co-resident workgroups of a CU (blocks b, b + 256, ...) get different levels
-    {
-        const unsigned lvl = (blockIdx.x >> 8) % 3u;
-        if (lvl == 1) __builtin_amdgcn_s_setprio(1);
-        if (lvl == 2) __builtin_amdgcn_s_setprio(2);
-    }
-#endif
 
     constexpr int KC = NM / 2;  // K chunks of 32 for the fp16 MFMA
     const int n_hidden = NH ? NH : p.n_hidden;
@@ -343,7 +300,6 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
     const char* Lwh = smem + p.L.wh;
     const char* Lwh_lo = smem + p.L.wh_lo;
     const char* Lwo = smem + p.L.wo;
-    const float* Lwo32 = reinterpret_cast<const float*>(smem + p.L.wo32);
     const float* Lbw1 = reinterpret_cast<const float*>(smem + p.L.bw1);
     const float* Lbb1 = reinterpret_cast<const float*>(smem + p.L.bb1);
     const float* Lbw2 = reinterpret_cast<const float*>(smem + p.L.bw2);
@@ -437,10 +393,6 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
         // v_permlane32_swap exchange the halves (3 sincosf per lane instead of 5).
         const float ysel = (g & 1) ? y1 : y0;
         float pe[PE_BANDS];
-#if (BSDFD_ABL & 1)
-#pragma unroll
-        for (int b = 0; b < PE_BANDS; ++b) pe[b] = ysel * (float)(1 << b);
-#else
         {
             const bool upper = (g >> 1) != 0;  // lanes 32..63: want cos; evaluate bands 3, 4
             float sv[3], cv[3];
@@ -464,7 +416,6 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
             pe[3] = upper ? cv[0] : __uint_as_float(got[0][1]);
             pe[4] = upper ? cv[1] : __uint_as_float(got[1][1]);
         }
-#endif
         const float yslab = g == 0 ? y0 : (g == 1 ? y1 : 0.0f);
 
         // conditioning part of layer 1 (constant across the Euler steps) and the base-density net
@@ -490,19 +441,12 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
             if (s < BASE_PE_BANDS) bz = mfma4(Lbw1[s * 64 + lane], b, bz);
             if (s == PE_BANDS) bz = mfma4(Lbw1[BASE_PE_BANDS * 64 + lane], b, bz);
         }
-#if (BSDFD_ABL & 2)
-#pragma unroll
-        for (int m = 0; m < NM; ++m) cacc[m] = zero4 + pe[0];
-#endif
         {
             const f32x4 w2 = *reinterpret_cast<const f32x4*>(Lbw2 + lane * 4);
             bo = *reinterpret_cast<const f32x4*>(Lbb2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) bo = mfma4(w2[r], silu(bz[r]), bo);
         }
-#if (BSDFD_ABL & 4)
-        bo = zero4 + pe[1];
-#endif
         // bo = (loc0, loc1, ls0, ls1) disk | (loc, log_scale, mu, kappa_raw) spherical
         float kappa = 0.0f;
         if (DOMAIN == BSDFD_DOMAIN_SPHERICAL) kappa = softplus(bo[3]) + 1e-3f;
@@ -555,15 +499,18 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
             }
         };
         float p0 = 1.0f;
-#if (BSDFD_ABL & 8)
-        if (op == OP_SAMPLE) p0 = bo[0];
-#else
         if (op == OP_SAMPLE) p0 = base_pdf(x0, x1);
-#endif
 
         // ---------------- T explicit Euler steps ---------------------------------------------------
         float acc = 1.0f;
         for (int t = 0; t < p.T; ++t) {
+            // The depth-unrolled spherical kernel (4 hidden layers: 48 + 4 weight-fragment registers) spilled 11 VGPRs to
+            // scratch at 3 waves/SIMD when the compiler hoisted every fragment load out of this loop (round 1: HBM traffic
+            // 1.14x the algorithmic bytes).  Any asm statement in the loop body stops that hoisting, so for THIS
+            // instantiation the fragments are re-read from LDS every step (13 conflict-free ds_read_b128 per step): 153
+            // VGPRs, no scratch, traffic 1.0x, +0.9 % kernel time (profiles/r02_ab/ab2: variant r32, sph8).  The disk
+            // kernel has no spills and keeps its fragments in registers (the same change costs it 2 %).
+            if (DOMAIN == BSDFD_DOMAIN_SPHERICAL && NM == 2 && NH == 4 && JAC) asm volatile("");
             // alpha = float32(t/T) resp. float32(1 - t/T) as torch forms them (python double, then
             // cast); t * (1/T) in fp64 differs from t/T by < 1 ulp(fp64), invisible after the cast.
             float alpha;
@@ -575,12 +522,6 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
                 alpha = (float)(reverse ? 1.0 - tf : tf);
             }
             f32x4 z[NM], zt0[NM], zt1[NM];
-            // an opaque zero: added to the LDS address of the weight fragments that should be RE-READ every step instead
-            // of being hoisted out of the loop into registers (the compiler cannot prove the address loop-invariant)
-            int opaque0 = 0;
-#if (BSDFD_EXP & 32)
-            asm volatile("" : "+v"(opaque0));
-#endif
             if (DOMAIN == BSDFD_DOMAIN_DISK) {
                 const float bs = sel4(g, x0, x1, alpha, 0.0f);
 #pragma unroll
@@ -591,11 +532,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
                 }
             } else {
                 float sp, cp;
-#if (BSDFD_EXP & 16)
                 sincos_enc(x1, sp, cp);
-#else
-                sincosf(x1, &sp, &cp);  // net input [theta, sin phi, cos phi], mlp_brdf_sampling.py:119-121
-#endif
                 const float bs = sel4(g, x0, sp, cp, alpha);
                 const float bt = sel4(g, 0.0f, cp, -sp, 0.0f);  // d/dphi of the input
 #pragma unroll
@@ -666,38 +603,14 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
                 // with the VALU work of the next measured no faster: on gfx950 a 16x16x32 MFMA hides
                 // only ~3 VALU issues, tools/ubench/mfma_overlap.hip — MFMA and VALU time add.)
                 constexpr bool SPLIT = (PREC == BSDFD_PREC_SPLIT3);
-                constexpr bool TSPLIT = SPLIT && (BSDFD_TPREC == 3);   // tangents: hi+lo operands
-                constexpr bool TWLO = SPLIT && (BSDFD_TPREC >= 2);     // tangents: W_lo product
+                constexpr bool TSPLIT = SPLIT && (kTangentPrec == 3);   // tangents: hi+lo operands
+                constexpr bool TWLO = SPLIT && (kTangentPrec >= 2);     // tangents: W_lo product
                 // NH > 0: fully unrolled.  NH == 0 (run-time depth) cannot be, and clang says so (-Wpass-failed,
                 // silenced in the build line); an explicit `unroll 1` there measured 13 % slower on the 64-wide net
 #pragma unroll
                 for (int layer = 0; layer < n_hidden; ++layer) {
                     const bool last = (layer == n_hidden - 1);
                     Frag bh[KC], bl[KC], b0h[KC], b0l[KC], b1h[KC], b1l[KC];
-                    // OUT_VALU: the 2-row output layer as fp32 dot products on the VALU.  The last hidden layer's
-                    // activations and tangents then need no hi/lo split (3 x 8 values per lane: 9 VALU each) and the six
-                    // 14/16-empty output MFMAs go away; the price is 8 FMAs per unit and an all-reduce of six partial sums
-                    // over the 4 lanes of a query.
-                    constexpr bool OUT_VALU = (BSDFD_EXP & 128) != 0;
-                    float pv0 = 0.f, pv1 = 0.f, p00 = 0.f, p01 = 0.f, p10 = 0.f, p11 = 0.f;
-                    // weight fragments of this layer: loaded asynchronously ahead of the activation math (ASYNC_W), or
-                    // by plain loads inside the K loop
-                    // (only the split3 + Jacobian 64-wide kernel: it runs 2 waves/SIMD at 225+ VGPRs; the fp16 teacher kernel
-                    // has 4 waves/SIMD to hide the latency and would lose that occupancy to the extra live registers)
-                    constexpr bool ASYNC_W = (NH == 0) && (NM == 4) && SPLIT && JAC && ((BSDFD_EXP & 64) != 0);
-                    constexpr int PRE_KC = 1;  // K chunks requested before the activation math; the next one flies behind the MFMAs
-                    f16x8 wfh[KC][NM], wfl[KC][NM];
-                    const size_t lbase = (size_t)layer * NM * KC * 64 * 16;
-                    if (ASYNC_W && !last) {
-#pragma unroll
-                        for (int kc = 0; kc < PRE_KC; ++kc)
-#pragma unroll
-                            for (int mo = 0; mo < NM; ++mo) {
-                                const size_t off = lbase + ((size_t)(mo * KC + kc) * 64 + lane) * 16;
-                                lds_read_b128_async(wfh[kc][mo], Lwh + off);
-                                if (SPLIT) lds_read_b128_async(wfl[kc][mo], Lwh_lo + off);
-                            }
-                    }
 #pragma unroll
                     for (int m = 0; m < NM; ++m) {
                         float hv[4], t0v[4], t1v[4];
@@ -711,20 +624,6 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
                             }
                         }
                         const int kc = m >> 1, q0 = 2 * (m & 1);
-                        if (OUT_VALU && last) {
-                            const f32x4 w0 = *reinterpret_cast<const f32x4*>(Lwo32 + ((m * 64 + lane) * 2 + 0) * 4);
-                            const f32x4 w1 = *reinterpret_cast<const f32x4*>(Lwo32 + ((m * 64 + lane) * 2 + 1) * 4);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                pv0 = fmaf(w0[r], hv[r], pv0);
-                                pv1 = fmaf(w1[r], hv[r], pv1);
-                                if (JAC) {
-                                    p00 = fmaf(w0[r], t0v[r], p00); p01 = fmaf(w0[r], t1v[r], p01);
-                                    p10 = fmaf(w1[r], t0v[r], p10); p11 = fmaf(w1[r], t1v[r], p11);
-                                }
-                            }
-                            continue;
-                        }
                         split_pack<SPLIT>(hv, bh[kc].p[q0], bh[kc].p[q0 + 1], bl[kc].p[q0], bl[kc].p[q0 + 1]);
                         if (JAC) {
                             split_pack<TSPLIT>(t0v, b0h[kc].p[q0], b0h[kc].p[q0 + 1], b0l[kc].p[q0], b0l[kc].p[q0 + 1]);
@@ -732,39 +631,18 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
                         }
                     }
                     if (!last) {
+                        const size_t lbase = (size_t)layer * NM * KC * 64 * 16;
                         f32x4 a[NM], a0[NM], a1[NM];
 #pragma unroll
                         for (int mo = 0; mo < NM; ++mo) { a[mo] = zero4; a0[mo] = zero4; a1[mo] = zero4; }
-#if (BSDFD_EXP & 2)
-                        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
                         for (int kc = 0; kc < KC; ++kc) {
                             f16x8 wh[NM], wl[NM];
-                            if (ASYNC_W) {
-                                if (NM == 4) {  // (the helper is written for 4 fragments)
-                                    lds_wait4(wfh[kc][0], wfh[kc][1], wfh[kc][2 % NM], wfh[kc][3 % NM]);
-                                    if (SPLIT) lds_wait4(wfl[kc][0], wfl[kc][1], wfl[kc][2 % NM], wfl[kc][3 % NM]);
-                                }
-                                if (kc + 1 < KC && kc + 1 >= PRE_KC) {  // next chunk: in flight behind this chunk's MFMAs
 #pragma unroll
-                                    for (int mo = 0; mo < NM; ++mo) {
-                                        const size_t off = lbase + ((size_t)(mo * KC + kc + 1) * 64 + lane) * 16;
-                                        lds_read_b128_async(wfh[(kc + 1) % KC][mo], Lwh + off);
-                                        if (SPLIT) lds_read_b128_async(wfl[(kc + 1) % KC][mo], Lwh_lo + off);
-                                    }
-                                }
-#pragma unroll
-                                for (int mo = 0; mo < NM; ++mo) { wh[mo] = wfh[kc][mo]; if (SPLIT) wl[mo] = wfl[kc][mo]; }
-                            } else {
-#pragma unroll
-                                for (int mo = 0; mo < NM; ++mo) {
-                                    const size_t off = lbase + ((size_t)(mo * KC + kc) * 64 + lane) * 16;
-                                    const bool re_hi = NH > 0 && DOMAIN == BSDFD_DOMAIN_SPHERICAL && ((BSDFD_RELOAD_HI >> layer) & 1);
-                                    const bool re_lo = NH > 0 && DOMAIN == BSDFD_DOMAIN_SPHERICAL && ((BSDFD_RELOAD_LO >> layer) & 1);
-                                    wh[mo] = *reinterpret_cast<const f16x8*>(Lwh + off + (re_hi ? opaque0 : 0));
-                                    if (SPLIT) wl[mo] = *reinterpret_cast<const f16x8*>(Lwh_lo + off + (re_lo ? opaque0 : 0));
-                                }
+                            for (int mo = 0; mo < NM; ++mo) {
+                                const size_t off = lbase + ((size_t)(mo * KC + kc) * 64 + lane) * 16;
+                                wh[mo] = *reinterpret_cast<const f16x8*>(Lwh + off);
+                                if (SPLIT) wl[mo] = *reinterpret_cast<const f16x8*>(Lwh_lo + off);
                             }
 #pragma unroll
                             for (int mo = 0; mo < NM; ++mo) {
@@ -772,41 +650,20 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
                                 if (JAC) { a0[mo] = mfma16(wh[mo], b0h[kc].v, a0[mo]); a1[mo] = mfma16(wh[mo], b1h[kc].v, a1[mo]); }
                             }
                             if (SPLIT) {
-#if !(BSDFD_ABL & 32)  // ablation: drop W_hi * x_lo  (p99 pdf error 1.8e-5 -> 3e-3 .. 1e-1)
 #pragma unroll
                                 for (int mo = 0; mo < NM; ++mo) {
                                     a[mo] = mfma16(wh[mo], bl[kc].v, a[mo]);
                                     if (JAC && TSPLIT) { a0[mo] = mfma16(wh[mo], b0l[kc].v, a0[mo]); a1[mo] = mfma16(wh[mo], b1l[kc].v, a1[mo]); }
                                 }
-#endif
-#if !(BSDFD_ABL & 16)  // ablation: drop W_lo * x_hi  (p99 pdf error 1.8e-5 -> 2e-3 .. 7e-2)
 #pragma unroll
                                 for (int mo = 0; mo < NM; ++mo) {
                                     a[mo] = mfma16(wl[mo], bh[kc].v, a[mo]);
                                     if (JAC && TWLO) { a0[mo] = mfma16(wl[mo], b0h[kc].v, a0[mo]); a1[mo] = mfma16(wl[mo], b1h[kc].v, a1[mo]); }
                                 }
-#endif
                             }
                         }
-#if (BSDFD_EXP & 2)
-                        __builtin_amdgcn_s_setprio(0);
-#endif
 #pragma unroll
                         for (int mo = 0; mo < NM; ++mo) { z[mo] = a[mo]; zt0[mo] = a0[mo]; zt1[mo] = a1[mo]; }
-                    } else if (OUT_VALU) {
-                        // all-reduce over the query's 4 lanes (lane ^ 16, lane ^ 32); every lane ends up with the totals,
-                        // so the state update and the determinant below stay lane-local (the weights carry the -ln 2
-                        // of the scaled-activation convention, build_image).
-                        auto allred = [](float x) {
-                            x += __shfl_xor(x, 16, 64);
-                            x += __shfl_xor(x, 32, 64);
-                            return x;
-                        };
-                        v[0] = allred(pv0); v[1] = allred(pv1);
-                        if (JAC) {
-                            d0[0] = allred(p00); d0[1] = allred(p10);
-                            d1[0] = allred(p01); d1[1] = allred(p11);
-                        }
                     } else {
                         // output layer: A rows (i&3) = {Wout_hi[0], Wout_hi[1], Wout_lo[0], Wout_lo[1]}, so
                         // e[0..1] = hi*hi + hi*lo and e[2..3] = lo*hi (+ lo*lo, ~2^-22): out = e[o] + e[o+2]
@@ -864,13 +721,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? BSDFD_WAVES32 : 2) v
                 pdf_sa = (ok ? pdf : 0.0f) * oz;
             } else {  // rendering/brdf_measured_spherical.py:79-91, bsdf_myresult.py:69-84
                 float st, ct, sp, cp;
-#if (BSDFD_EXP & 16)
                 sincos_enc(x0, st, ct);
                 sincos_enc(x1, sp, cp);
-#else
-                sincosf(x0, &st, &ct);
-                sincosf(x1, &sp, &cp);
-#endif
                 if (!(st > 0.00005f)) pdf = 0.0f;
                 if (p.io == IO_PLUGIN && !(ct > 0.0f)) pdf = 0.0f;
                 ox = cp * st; oy = sp * st; oz = ct;
@@ -976,7 +828,6 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
         if (prec == BSDFD_PREC_SPLIT3) off += (NH - 1) * NM * KC * 64 * 16;
         L.wo = off; off += KC * 64 * 16;
     }
-    L.wo32 = off; off += NM * 64 * 8 * 4;  // fp32 output-layer weights per lane-unit: [m][lane][o][r]
     L.bw1 = off; off += (BASE_PE_BANDS + 1) * 64 * 4;
     L.bb1 = off; off += 64 * 16;
     L.bw2 = off; off += 64 * 16;
@@ -1007,11 +858,6 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
         }
     }
     for (int r = 0; r < 4; ++r) F(L.bb2)[r] = d.base_b2[r];
-    for (int m = 0; m < NM; ++m)
-        for (int l = 0; l < 64; ++l)
-            for (int o = 0; o < 2; ++o)
-                for (int r = 0; r < 4; ++r)
-                    F(L.wo32)[((m * 64 + l) * 2 + o) * 4 + r] = d.w_out[o * W + 16 * m + 4 * (l >> 4) + r];
 
     if (prec == BSDFD_PREC_F32) {
         for (int layer = 0; layer < NH - 1; ++layer)
@@ -1484,6 +1330,6 @@ float bsdfd_last_kernel_ms(bsdfd_handle h) {
 }
 
 const char* bsdfd_last_error(void) { return g_err.c_str(); }
-const char* bsdfd_version(void) { return "bsdfd 0.1 (gfx950)"; }
+const char* bsdfd_version(void) { return "bsdfd 0.2 (gfx950)"; }
 
 }  // extern "C"
