@@ -54,6 +54,17 @@ struct Field {
         for (auto s : shape) n *= (size_t)s;
         return n;
     }
+    // element count with the shape fields validated: every dimension <= 2^26 and no wrap-around of the product (a
+    // crafted shape that wraps to a small product would pass the "fits in the file" test and then index out of bounds)
+    bool count_checked(size_t* out) const {
+        size_t n = 1;
+        for (auto s : shape) {
+            if (s > (1ull << 26)) return false;
+            if (__builtin_mul_overflow(n, (size_t)s, &n)) return false;
+        }
+        *out = n;
+        return true;
+    }
 };
 
 __device__ __forceinline__ float elevation(float x, float y, float z) {  // 2 asin(|d - z| / 2)
@@ -284,7 +295,10 @@ int bsdfd_measured_create_from_file(const char* path, bsdfd_measured_handle* out
         f.shape.resize(nd);
         std::memcpy(f.shape.data(), raw.data() + pos, 8 * (size_t)nd); pos += 8 * (size_t)nd;
         if (f.dtype < 1 || f.dtype > 11) return bsdfd_fail_(BSDFD_EIO, std::string(path) + ": bad dtype in field " + name);
-        if (off > raw.size() || f.count() * dtype_size[f.dtype] > raw.size() - off)
+        size_t cnt = 0, bytes = 0;
+        if (!f.count_checked(&cnt) || __builtin_mul_overflow(cnt, (size_t)dtype_size[f.dtype], &bytes))
+            return bsdfd_fail_(BSDFD_EIO, std::string(path) + ": implausible shape in field " + name);
+        if (off > raw.size() || bytes > raw.size() - off)
             return bsdfd_fail_(BSDFD_EIO, std::string(path) + ": field " + name + " exceeds the file");
         f.ptr = raw.data() + off;
         fields[name] = f;
@@ -300,6 +314,11 @@ int bsdfd_measured_create_from_file(const char* path, bsdfd_measured_handle* out
     if (!phi || !theta || !sigma || !ndf || !vndf || !rgb || !jac)
         return bsdfd_fail_(BSDFD_EIO, std::string(path) + ": expected fp32 fields phi_i, theta_i, sigma, ndf, vndf, rgb and u8 "
                                                            "jacobian (spectral files are not supported; use the *_rgb.bsdf flavour)");
+    for (const Field* f : {phi, theta, sigma, ndf, vndf, rgb})  // table extents are used as int indices below
+        for (auto dim : f->shape)
+            if (dim < 1 || dim > (1u << 20))
+                return bsdfd_fail_(BSDFD_EIO, std::string(path) + ": table dimension out of range [1, 2^20]");
+    if (jac->shape[0] < 1) return bsdfd_fail_(BSDFD_EIO, std::string(path) + ": empty jacobian field");
     const int n_phi = (int)phi->shape[0], n_theta = (int)theta->shape[0];
     if ((int)vndf->shape[0] != n_phi || (int)vndf->shape[1] != n_theta || (int)rgb->shape[0] != n_phi ||
         (int)rgb->shape[1] != n_theta || rgb->shape[2] != 3 || vndf->shape[2] < 2 || vndf->shape[3] < 2 ||

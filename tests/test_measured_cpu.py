@@ -120,3 +120,56 @@ def test_agrees_with_the_shipped_network(gt):
 
 def O_lum(rgb):
     return 0.2126 * rgb[:, 0] + 0.7152 * rgb[:, 1] + 0.0722 * rgb[:, 2]
+
+
+def _field_records(raw):
+    """(name -> (ndim, offset of the first u64 shape entry)) of a tensor file's header."""
+    import struct
+    nf = struct.unpack_from("<I", raw, 14)[0]
+    pos, out = 18, {}
+    for _ in range(nf):
+        nl = struct.unpack_from("<H", raw, pos)[0]
+        name = raw[pos + 2: pos + 2 + nl].decode()
+        nd = struct.unpack_from("<H", raw, pos + 2 + nl)[0]
+        shape_at = pos + 2 + nl + 2 + 1 + 8
+        out[name] = (nd, shape_at)
+        pos = shape_at + 8 * nd
+    return out
+
+
+def test_native_loader_rejects_malformed_tensor_files(tmp_path):
+    """The C loader (bsdfd_measured_create_from_file) validates the shape fields BEFORE any device work: zero or
+    oversized dimensions, products that wrap around 2^64, fields that exceed the file, truncated files.  (Runs without a
+    GPU: every case fails in the parser.)"""
+    import ctypes as C
+    import struct
+    from bsdf_diffusion_sampling_amd import _lib
+    L = _lib.lib()
+    raw = open(FIXTURE, "rb").read()
+    rec = _field_records(raw)
+    assert set(rec) >= {"phi_i", "theta_i", "sigma", "ndf", "vndf", "rgb", "jacobian"}
+
+    def attempt(data, expect):
+        p = tmp_path / "bad.bsdf"
+        p.write_bytes(bytes(data))
+        h = C.c_void_p()
+        rc = L.bsdfd_measured_create_from_file(str(p).encode(), C.byref(h))
+        msg = L.bsdfd_last_error().decode()
+        assert rc == 3 and h.value is None and expect in msg, (rc, msg)   # BSDFD_EIO
+
+    def patched(name, dims):
+        b = bytearray(raw)
+        nd, at = rec[name]
+        assert len(dims) == nd
+        struct.pack_into("<%dQ" % nd, b, at, *dims)
+        return b
+
+    attempt(patched("theta_i", [0]), "out of range")                          # empty table
+    attempt(patched("phi_i", [0]), "out of range")
+    attempt(patched("vndf", [1 << 26] * 4), "implausible shape")              # 2^104 elements: the product wraps
+    attempt(patched("vndf", [1 << 63, 2, 1, 1]), "implausible shape")         # one absurd dimension
+    attempt(patched("rgb", [1, 8, 3, 1 << 24, 1 << 24]), "exceeds the file")   # plausible dimensions, absurd product
+    attempt(patched("ndf", [1 << 20, 1 << 20]), "exceeds the file")
+    attempt(raw[: len(raw) // 2], "exceeds the file")                          # truncated payload
+    attempt(raw[:40], "truncated header")
+    attempt(b"not a tensor file at all", "not a tensor file")
