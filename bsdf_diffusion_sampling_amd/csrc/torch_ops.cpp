@@ -5,9 +5,10 @@
 // a device guard, the CURRENT stream of the tensors' device, outputs allocated by torch, raw pointers handed to
 // the native call.  This file is that layer for bsdfd: every operator checks its tensors, takes the current HIP
 // stream of their device and calls one entry point of include/bsdfd.h — no arithmetic here.  It exists next to
-// the ctypes shim (sampler.py) because a ctypes call costs ~9.5 us of host time, as much as the kernel itself for a
-// 4 Ki-query wavefront; the dispatcher path costs ~2 us, and the operators are visible to torch tooling
-// (torch.ops.bsdfd.*, stream-capturable, no GIL-held pointer marshalling).
+// the ctypes shim (sampler.py) because a ctypes call costs 9.8 us of host time — more than the 8.3 us kernel of a
+// 4 Ki-query wavefront (hipGraph replay), so small wavefronts were host-bound; through the dispatcher a call issues in
+// 7.9 us and the same loop runs at 8.5 us per call, i.e. kernel-bound (tools/host_overhead.py, round 2).  The operators
+// are also visible to torch tooling (torch.ops.bsdfd.*, stream-capturable, no GIL-held pointer marshalling).
 //
 // Built in-tree (no hipify pass, no CUDA spellings): g++ against torch's headers and libbsdfd.so, loaded with
 // torch.ops.load_library (bsdf_diffusion_sampling_amd/torch_ext.py).
