@@ -152,6 +152,34 @@ class MaterialTable:
     def _chk_in(self, t, cols, name, n=None):
         return self.samplers[0]._chk(t, cols, name, n)
 
+    # -- bucketed flow: a renderer keeps a wavefront in bucket order across its sample() and pdf() calls and scatters
+    # once at the end, instead of gathering the inputs and scattering the outputs in every call -----------------------
+    def _plan_bucketed(self, plan):
+        if not isinstance(plan, tuple):
+            raise ValueError("bucketed=True needs a plan from bucket()")
+        perm, counts = self._buckets(plan)
+        counts = counts[: len(self)]
+        n_mat = sum(counts)
+        return perm[:n_mat] if n_mat != perm.shape[0] else perm, counts, list(__import__("itertools").accumulate(counts))
+
+    def gather(self, plan, *tensors):
+        """Rows of the lanes that carry a material, in bucket order (what ``bucketed=True`` calls take and return)."""
+        rows, _, _ = self._plan_bucketed(plan)
+        out = tuple(t[rows].contiguous() for t in tensors)
+        return out[0] if len(out) == 1 else out
+
+    def scatter(self, plan, *tensors):
+        """Inverse of ``gather``: bucket-ordered results back to the callers' lane order (lanes without a material: 0)."""
+        perm, _ = plan
+        rows, _, _ = self._plan_bucketed(plan)
+        n = perm.shape[0]
+        out = []
+        for t in tensors:
+            full = (torch.empty if rows.shape[0] == n else torch.zeros)((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            full[rows] = t
+            out.append(full)
+        return out[0] if len(out) == 1 else tuple(out)
+
     def bucket(self, material_id: torch.Tensor, extra_bins: int = 0):
         """Bucket a wavefront once and reuse the plan for its sample() and pdf() calls (a renderer asks both
         for the same intersections): pass the returned value in place of ``material_id``.  The stable sort
@@ -161,15 +189,23 @@ class MaterialTable:
         return self._buckets(material_id, extra_bins)
 
     def sample(self, material_id: torch.Tensor, wi: torch.Tensor, seed: int = 0, offset: int = 0,
-               T: Optional[int] = None, x0: Optional[torch.Tensor] = None, segmented: bool = True):
+               T: Optional[int] = None, x0: Optional[torch.Tensor] = None, segmented: bool = True,
+               bucketed: bool = False):
         """wi [N,3], material_id [N] -> (wo [N,3], pdf_sa [N]) in the callers' order.
         The Philox counter of a query is ``offset + its row in the bucketed (sorted-by-material)
-        array``, identical for the segmented and the per-bucket path."""
+        array``, identical for the segmented and the per-bucket path.  ``bucketed=True``: ``material_id`` is a
+        plan, ``wi`` / ``x0`` are already in bucket order (``gather(plan, wi)``) and the results stay in it."""
         wi = self._chk_in(wi, 3, "wi")
         x0 = self._chk_in(x0, 2, "x0", wi.shape[0])
-        rows, counts, seg_end = self._plan(material_id, wi.shape[0])
-        wi_s = wi[rows].contiguous()
-        x0_s = None if x0 is None else x0[rows].contiguous()
+        if bucketed:
+            rows, counts, seg_end = self._plan_bucketed(material_id)
+            if wi.shape[0] != rows.shape[0]:
+                raise ValueError(f"bucketed wi has {wi.shape[0]} rows, the plan has {rows.shape[0]} material lanes")
+            wi_s, x0_s = wi, x0
+        else:
+            rows, counts, seg_end = self._plan(material_id, wi.shape[0])
+            wi_s = wi[rows].contiguous()
+            x0_s = None if x0 is None else x0[rows].contiguous()
         wo_s = torch.empty_like(wi_s)
         pdf_s = torch.empty(wi_s.shape[0], dtype=torch.float32, device=wi.device)
         if segmented:
@@ -188,6 +224,8 @@ class MaterialTable:
                                                T=self.T[m] if T is None else T, variant=self.variant[m],
                                                seed=seed, offset=offset + lo, out=(wo_s[sl], pdf_s[sl]))
                 lo += n
+        if bucketed:
+            return wo_s, pdf_s
         mk = torch.empty if rows.shape[0] == wi.shape[0] else torch.zeros  # lanes without a material: zeros
         wo = mk(wi.shape, dtype=torch.float32, device=wi.device)
         pdf = mk(wi.shape[0], dtype=torch.float32, device=wi.device)
@@ -226,11 +264,17 @@ class MaterialTable:
         return wo, po, pl
 
     def pdf(self, material_id: torch.Tensor, wi: torch.Tensor, wo: torch.Tensor, T: Optional[int] = None,
-            segmented: bool = True):
+            segmented: bool = True, bucketed: bool = False):
         wi = self._chk_in(wi, 3, "wi")
         wo = self._chk_in(wo, 3, "wo", wi.shape[0])
-        rows, counts, seg_end = self._plan(material_id, wi.shape[0])
-        wi_s, wo_s = wi[rows].contiguous(), wo[rows].contiguous()
+        if bucketed:
+            rows, counts, seg_end = self._plan_bucketed(material_id)
+            if wi.shape[0] != rows.shape[0]:
+                raise ValueError(f"bucketed wi has {wi.shape[0]} rows, the plan has {rows.shape[0]} material lanes")
+            wi_s, wo_s = wi, wo
+        else:
+            rows, counts, seg_end = self._plan(material_id, wi.shape[0])
+            wi_s, wo_s = wi[rows].contiguous(), wo[rows].contiguous()
         pdf_s = torch.empty(wi_s.shape[0], dtype=torch.float32, device=wi.device)
         if segmented:
             with torch.cuda.device(wi.device):
@@ -245,6 +289,8 @@ class MaterialTable:
                 self.samplers[m].plugin_pdf(wi_s[sl], wo_s[sl], T=self.T[m] if T is None else T,
                                             variant=self.variant[m], out=pdf_s[sl])
                 lo += n
+        if bucketed:
+            return pdf_s
         pdf = (torch.empty if rows.shape[0] == wi.shape[0] else torch.zeros)(wi.shape[0], dtype=torch.float32,
                                                                              device=wi.device)
         pdf[rows] = pdf_s

@@ -150,6 +150,17 @@ def test_plan_with_extra_bins_serves_sample_and_pdf():
         p = tab.pdf(plan, wi, wo, segmented=seg)
         assert torch.count_nonzero(p[~mat]) == 0
         assert torch.equal(p[mat], tab.pdf(ids[mat], wi[mat].contiguous(), wo[mat].contiguous(), segmented=seg))
+    # bucketed flow (gather once, keep bucket order through sample() and pdf(), scatter once) == the per-call flow
+    wi_b = tab.gather(plan, wi)
+    wo_b, pdf_b = tab.sample(plan, wi_b, seed=4, offset=7, bucketed=True)
+    p_b = tab.pdf(plan, wi_b, wo_b, bucketed=True)
+    wo_r, pdf_r, p_r = tab.scatter(plan, wo_b, pdf_b, p_b)
+    wo_c, pdf_c = tab.sample(plan, wi, seed=4, offset=7)
+    assert torch.equal(wo_r, wo_c) and torch.equal(pdf_r, pdf_c) and torch.equal(p_r, tab.pdf(plan, wi, wo_c))
+    with pytest.raises(ValueError):
+        tab.sample(plan, wi, bucketed=True)                           # caller-order array passed as bucketed
+    with pytest.raises(ValueError):
+        tab.sample(ids, wi_b, bucketed=True)                          # bucketed needs a plan
     wl = _wi("disk", n, 6)
     wo_f, po_f, pl_f = tab.sample_pdf(plan, wi, wl, seed=4, offset=7)
     assert torch.count_nonzero(wo_f[~mat]) == 0 and torch.count_nonzero(pl_f[~mat]) == 0
