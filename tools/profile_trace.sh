@@ -1,0 +1,11 @@
+#!/bin/bash
+# Kernel-trace-only rocprofv3 pass of a bench.py workload (no PMC passes): tools/profile_trace.sh <tag> --workload <name>
+set -u
+TAG=${1:-r02t}; shift || true
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $REPO/bench.py --no-cpu-baseline --no-secondary $* > $OUT/trace.log 2>&1
+grep -h "^{" $OUT/trace.log | tail -1 > $OUT/bench_line.json
+head -6 $OUT/trace/trace_kernel_stats.csv
