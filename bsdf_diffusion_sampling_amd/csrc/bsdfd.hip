@@ -509,8 +509,9 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             // 1.14x the algorithmic bytes).  Any asm statement in the loop body stops that hoisting, so for THIS
             // instantiation the fragments are re-read from LDS every step (13 conflict-free ds_read_b128 per step): 153
             // VGPRs, no scratch, traffic 1.0x, +0.9 % kernel time (profiles/r02_ab/ab2: variant r32, sph8).  The disk
-            // kernel has no spills and keeps its fragments in registers (the same change costs it 2 %).
-            if (DOMAIN == BSDFD_DOMAIN_SPHERICAL && NM == 2 && NH == 4 && JAC) asm volatile("");
+            // kernel has no spills and keeps its fragments in registers (the same change costs it 2 %).  The depth-unrolled
+            // 64 x 6 kernels could not hold 5 layers of 64-wide fragments in registers at all: same treatment.
+            if (DOMAIN == BSDFD_DOMAIN_SPHERICAL && ((NM == 2 && NH == 4 && JAC) || (NM == 4 && NH == 6))) asm volatile("");
             // alpha = float32(t/T) resp. float32(1 - t/T) as torch forms them (python double, then
             // cast); t * (1/T) in fp64 differs from t/T by < 1 ulp(fp64), invisible after the cast.
             float alpha;
@@ -923,7 +924,11 @@ const void* kernel_ptr(int domain, int nm, int n_hidden, int prec, int mode) {
     }
     if (nm == 2) return n_hidden == 4 ? kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 2, 4>(prec, mode)
                                       : kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 2, 0>(prec, mode);
-    // the 64-wide nets keep the run-time loop: fully unrolled, 6 layers of 64-wide fragments spill
+    // other 64-wide depths keep the run-time layer loop
+    // the reference's 64 x 6 teacher (NN_cond_pos_spherical_complicate) gets a depth-unrolled instantiation too: with the
+    // per-step LDS re-read of the fragments (see the Euler loop) it needs 121 (fp16) / 231 (split3) VGPRs and no scratch;
+    // A/B against the run-time-depth kernel: teacher -1.4 %, split3 -0.2 .. -2 % (profiles/r02_ab/ab6)
+    if (n_hidden == 6) return kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 4, 6>(prec, mode);
     return kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 4, 0>(prec, mode);
 }
 inline int threads_for(int nm) { return nm == 2 ? 256 : 512; }
