@@ -1,5 +1,5 @@
-// Host-side loaders (RGL tensor file, .bsdfw weight file) driven under AddressSanitizer on the CPU build: every argument is
-// handed to both loaders; malformed files must come back as BSDFD_EIO without an ASan report (tests/test_host_cpu.py).
+// Host-side loaders (RGL tensor file, .bsdfw weight file) driven under the address sanitizer on the CPU build (tools/asan/run_loaders_asan.py): every argument is
+// handed to both loaders; malformed files must come back as BSDFD_EIO without an ASan report.
 // GPU ASan is not available on this pool, so only the parsers — which run before any device call — are covered.
 #include <cstdio>
 #include <cstdlib>
