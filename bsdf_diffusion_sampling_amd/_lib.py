@@ -31,6 +31,7 @@ EXPORTS = (
     "bsdfd_plugin_sample_pdf_multi",
     "bsdfd_flow_samples_only", "bsdfd_wf_primary", "bsdfd_wf_shade",
     "bsdfd_positional_encoding", "bsdfd_bucket_workspace_bytes", "bsdfd_bucket_by_material",
+    "bsdfd_gather_lanes", "bsdfd_scatter_lanes",
     "bsdfd_measured_create_from_file", "bsdfd_measured_destroy", "bsdfd_measured_get_info", "bsdfd_measured_eval",
     "bsdfd_measured_sample_weight",
     "bsdfd_set_profiling", "bsdfd_profile_read", "bsdfd_last_kernel_ms", "bsdfd_shader_clock_mhz",
@@ -123,6 +124,8 @@ def lib():
     L.bsdfd_bucket_workspace_bytes.argtypes = [i64, i32]
     L.bsdfd_bucket_workspace_bytes.restype = i64
     L.bsdfd_bucket_by_material.argtypes = [fp, i64, i32, fp, fp, fp, i64, vp]
+    L.bsdfd_gather_lanes.argtypes = [fp, i64, fp, fp, vp]
+    L.bsdfd_scatter_lanes.argtypes = [fp, i64, fp, fp, fp, fp, fp, fp, vp]
     L.bsdfd_set_profiling.argtypes = [vp, i32]
     L.bsdfd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]
     L.bsdfd_last_kernel_ms.argtypes = [vp]

@@ -162,7 +162,55 @@ __global__ __launch_bounds__(BK_THREADS) void bucket_scatter_kernel(const long l
 
 }  // namespace
 
+// Lane-order gather / scatter around the bucketed flow (HBM-bound streaming passes; 12-B rows, so one side of each is
+// uncoalesced by nature — one pass moving all arrays of a wavefront beats one torch index kernel per array).
+__global__ __launch_bounds__(256) void gather_wi_kernel(const long long* __restrict__ perm, long long n,
+                                                        const float* __restrict__ wi, float* __restrict__ wi_b) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long s = perm[i];
+    const float a = wi[s * 3 + 0], b = wi[s * 3 + 1], c = wi[s * 3 + 2];
+    wi_b[i * 3 + 0] = a; wi_b[i * 3 + 1] = b; wi_b[i * 3 + 2] = c;
+}
+__global__ __launch_bounds__(256) void scatter_results_kernel(const long long* __restrict__ perm, long long n,
+                                                              const float* __restrict__ wo_b, const float* __restrict__ pdf_b,
+                                                              const float* __restrict__ pdf2_b, float* __restrict__ wo,
+                                                              float* __restrict__ pdf, float* __restrict__ pdf2) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long d = perm[i];
+    if (wo_b) {
+        const float a = wo_b[i * 3 + 0], b = wo_b[i * 3 + 1], c = wo_b[i * 3 + 2];
+        wo[d * 3 + 0] = a; wo[d * 3 + 1] = b; wo[d * 3 + 2] = c;
+    }
+    if (pdf_b) pdf[d] = pdf_b[i];
+    if (pdf2_b) pdf2[d] = pdf2_b[i];
+}
+
 extern "C" {
+
+int bsdfd_gather_lanes(const int64_t* perm, int64_t n, const float* wi, float* wi_b, void* stream) {
+    if (n < 0) return bsdfd_fail_(BSDFD_EINVAL, "N must be >= 0");
+    if (n == 0) return BSDFD_OK;
+    if (!perm || !wi || !wi_b) return bsdfd_fail_(BSDFD_EINVAL, "null pointer");
+    if ((n + 255) / 256 > 0x7fffffffLL) return bsdfd_fail_(BSDFD_EINVAL, "N too large");
+    hipLaunchKernelGGL(gather_wi_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const long long*>(perm), (long long)n, wi, wi_b);
+    HIP_TRY(hipGetLastError());
+    return BSDFD_OK;
+}
+
+int bsdfd_scatter_lanes(const int64_t* perm, int64_t n, const float* wo_b, const float* pdf_b, const float* pdf2_b, float* wo,
+                        float* pdf, float* pdf2, void* stream) {
+    if (n < 0) return bsdfd_fail_(BSDFD_EINVAL, "N must be >= 0");
+    if (n == 0) return BSDFD_OK;
+    if (!perm || (wo_b && !wo) || (pdf_b && !pdf) || (pdf2_b && !pdf2)) return bsdfd_fail_(BSDFD_EINVAL, "null pointer");
+    if ((n + 255) / 256 > 0x7fffffffLL) return bsdfd_fail_(BSDFD_EINVAL, "N too large");
+    hipLaunchKernelGGL(scatter_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const long long*>(perm), (long long)n, wo_b, pdf_b, pdf2_b, wo, pdf, pdf2);
+    HIP_TRY(hipGetLastError());
+    return BSDFD_OK;
+}
 
 int64_t bsdfd_bucket_workspace_bytes(int64_t n, int32_t n_materials) {
     if (n < 0 || n_materials < 1) return 0;

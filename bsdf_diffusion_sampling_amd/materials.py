@@ -163,19 +163,43 @@ class MaterialTable:
         return perm[:n_mat] if n_mat != perm.shape[0] else perm, counts, list(__import__("itertools").accumulate(counts))
 
     def gather(self, plan, *tensors):
-        """Rows of the lanes that carry a material, in bucket order (what ``bucketed=True`` calls take and return)."""
+        """Rows of the lanes that carry a material, in bucket order (what ``bucketed=True`` calls take and return).
+        A single fp32 [N,3] array (the wavefront's ``wi``) goes through the native one-pass kernel."""
         rows, _, _ = self._plan_bucketed(plan)
+        if (len(tensors) == 1 and tensors[0].is_cuda and tensors[0].dtype == torch.float32 and tensors[0].dim() == 2
+                and tensors[0].shape[1] == 3 and tensors[0].is_contiguous() and rows.is_contiguous()):
+            wi = tensors[0]
+            out = torch.empty((rows.shape[0], 3), dtype=torch.float32, device=wi.device)
+            with torch.cuda.device(wi.device):
+                _lib.check(_lib.lib().bsdfd_gather_lanes(C.c_void_p(rows.data_ptr()), rows.shape[0], C.c_void_p(wi.data_ptr()),
+                                                         C.c_void_p(out.data_ptr()),
+                                                         C.c_void_p(torch.cuda.current_stream(wi.device).cuda_stream)))
+            return out
         out = tuple(t[rows].contiguous() for t in tensors)
         return out[0] if len(out) == 1 else out
 
     def scatter(self, plan, *tensors):
-        """Inverse of ``gather``: bucket-ordered results back to the callers' lane order (lanes without a material: 0)."""
+        """Inverse of ``gather``: bucket-ordered results back to the callers' lane order (lanes without a material: 0).
+        The usual triple of a wavefront — (wo [n,3], pdf [n], pdf [n]) or (wo, pdf) — is written in ONE native pass."""
         perm, _ = plan
         rows, _, _ = self._plan_bucketed(plan)
-        n = perm.shape[0]
+        n, k = perm.shape[0], rows.shape[0]
+        mk = torch.empty if k == n else torch.zeros
+
+        def f32c(t, *shape):
+            return t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape
+        if (len(tensors) in (2, 3) and f32c(tensors[0], k, 3) and all(f32c(t, k) for t in tensors[1:]) and rows.is_contiguous()):
+            dev = tensors[0].device
+            full = [mk((n, 3), dtype=torch.float32, device=dev)] + [mk((n,), dtype=torch.float32, device=dev) for _ in tensors[1:]]
+            p = [C.c_void_p(t.data_ptr()) for t in tensors] + [None] * (3 - len(tensors))
+            q = [C.c_void_p(t.data_ptr()) for t in full] + [None] * (3 - len(tensors))
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().bsdfd_scatter_lanes(C.c_void_p(rows.data_ptr()), k, p[0], p[1], p[2], q[0], q[1], q[2],
+                                                          C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            return tuple(full)
         out = []
         for t in tensors:
-            full = (torch.empty if rows.shape[0] == n else torch.zeros)((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            full = mk((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             full[rows] = t
             out.append(full)
         return out[0] if len(out) == 1 else tuple(out)

@@ -187,6 +187,14 @@ int64_t bsdfd_bucket_workspace_bytes(int64_t N, int32_t n_materials);
 int bsdfd_bucket_by_material(const int64_t* material_id, int64_t N, int32_t n_materials, int64_t* perm,
                              int64_t* counts, void* workspace, int64_t workspace_bytes, void* hip_stream);
 
+/* Bucket order <-> lane order around a run of bucketed calls (a renderer keeps a wavefront in bucket order across its
+ * sample() and pdf() calls): wi_b[i] = wi[perm[i]] for the first n entries of perm (the lanes that carry a material), and
+ * the inverse for the results, all arrays of a wavefront in ONE pass (NULL = skip that array): wo[perm[i]] = wo_b[i],
+ * pdf[perm[i]] = pdf_b[i], pdf2[perm[i]] = pdf2_b[i].  Lanes not named by perm[0..n) are left untouched. */
+int bsdfd_gather_lanes(const int64_t* perm, int64_t n, const float* wi, float* wi_b, void* hip_stream);
+int bsdfd_scatter_lanes(const int64_t* perm, int64_t n, const float* wo_b, const float* pdf_b, const float* pdf2_b,
+                        float* wo, float* pdf, float* pdf2, void* hip_stream);
+
 /* ---- ground-truth evaluator for eval(): RGL measured BSDF (rgb tensor files) -----------------------
  * Replaces, for the plugins' eval() / sample-weight / firefly rule, the Mitsuba `measured` BSDF the
  * reference builds in rendering/brdf_measured_disk.py:36-42 (`mi.load_dict({'type': 'measured',
