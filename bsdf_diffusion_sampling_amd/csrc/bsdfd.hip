@@ -65,7 +65,7 @@ constexpr int MAX_SEG = 64;  // materials per segmented launch (the descriptors 
 enum { IO_OPERATOR = 0, IO_PLUGIN = 1, IO_PLUGIN_FULLSPHERE = 2 };
 
 struct ImgLayout {  // byte offsets into the weight image (identical in global memory and LDS)
-    int win, wc, wh, wh_lo, wo, bw1, bb1, bw2, bb2, total;
+    int win, wc, wh, wh_lo, wo, wf, wf_lo, bw1, bb1, bw2, bb2, total;
 };
 
 struct KParams {
@@ -159,6 +159,16 @@ __device__ __forceinline__ void sincos_bounded(float a, float& s_out, float& c_o
 __device__ __forceinline__ void sincos_enc(float a, float& s, float& c) {
     if (__builtin_expect(fabsf(a) <= 1024.0f, 1)) sincos_bounded(a, s, c);
     else sincosf(a, &s, &c);
+}
+
+// LDS reads the compiler does not schedule or wait for: issued early (top of an Euler step) and waited for just before
+// the first MFMA that consumes them; the wait statement names every destination as "+v", which orders all consumers
+// behind it (cdna_hip_programming.md §5.7, form (ii)).  hipcc itself places a ds_read right in front of its use.
+__device__ __forceinline__ void lds_read_b128_async(f16x8& dst, const char* p) {
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"((unsigned)(uintptr_t)p) : "memory");
+}
+__device__ __forceinline__ void lds_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
 }
 
 union Frag {  // one MFMA B fragment: the lane's 8 K-values of a chunk
@@ -288,6 +298,38 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
     __syncthreads();
 
     constexpr int KC = NM / 2;  // K chunks of 32 for the fp16 MFMA
+    // FOLD_L1 (disk nets, fp16 MFMA paths): the layer-1 tangents are t_i = g (.) w_i with w_i = W1[:, i] CONSTANT, so
+    // W2 t_i = (W2 diag(w_i)) g.  The host packs the two folded matrices (L.wf) and the first hidden layer splits ONE
+    // vector (g) instead of two tangents: one hi/lo split and two multiplies per unit less, the same MFMA count.
+    // Within-run A/B: -5.5 % (T = 8), -4.7 % (T = 4), -4.9 % (fused sample+pdf), accuracy unchanged (profiles/r02_ab/ab7).  The spherical analogue
+    // (three folded matrices, d/dphi = cos(phi) F_sin g - sin(phi) F_cos g: +6 fp16 MFMAs, -2 fp32 MFMAs, one split less)
+    // was built and measured at +-0.2 %: not kept.
+    constexpr bool FOLD_L1 = JAC && NM == 2 && PREC != BSDFD_PREC_F32 && DOMAIN == BSDFD_DOMAIN_DISK && NH == 3;
+    // With the folded matrices all register-resident the disk kernel wants 4 VGPRs more than 3 waves/SIMD allow (20 B/lane
+    // of scratch, HBM traffic 1.23x the algorithmic bytes; -5 % kernel time).  PIN: this kernel loads the fragments it
+    // keeps resident EXPLICITLY here (hidden layers, output layer, folded hi parts) and fetches the folded LO parts (4
+    // fragments, live in the first hidden layer only) from LDS at the top of every step with asynchronous reads: no
+    // scratch, traffic 1.0x, -3.7 % kernel time (profiles/r02_ab/ab7c: foldA = all resident, pin2 = this; letting the
+    // compiler place those 4 reads costs another 2 % — it puts them right in front of their MFMAs).
+    constexpr bool PIN = FOLD_L1 && !FUSED && KC == 1;
+    f16x8 P_wh[2][NM], P_wl[2][NM], P_wo, P_f0h[NM], P_f1h[NM];
+    if (PIN) {
+        const int ln = threadIdx.x & 63;
+#pragma unroll
+        for (int l = 0; l < 2; ++l)
+#pragma unroll
+            for (int mo = 0; mo < NM; ++mo) {
+                const size_t off = (size_t)l * NM * KC * 64 * 16 + ((size_t)mo * 64 + ln) * 16;
+                P_wh[l][mo] = *reinterpret_cast<const f16x8*>(smem + p.L.wh + off);
+                if (PREC == BSDFD_PREC_SPLIT3) P_wl[l][mo] = *reinterpret_cast<const f16x8*>(smem + p.L.wh_lo + off);
+            }
+        P_wo = *reinterpret_cast<const f16x8*>(smem + p.L.wo + (size_t)ln * 16);
+#pragma unroll
+        for (int mo = 0; mo < NM; ++mo) {
+            P_f0h[mo] = *reinterpret_cast<const f16x8*>(smem + p.L.wf + ((size_t)mo * 64 + ln) * 16);
+            P_f1h[mo] = *reinterpret_cast<const f16x8*>(smem + p.L.wf + (size_t)NM * KC * 64 * 16 + ((size_t)mo * 64 + ln) * 16);
+        }
+    }
     const int n_hidden = NH ? NH : p.n_hidden;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4;
@@ -300,6 +342,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
     const char* Lwh = smem + p.L.wh;
     const char* Lwh_lo = smem + p.L.wh_lo;
     const char* Lwo = smem + p.L.wo;
+    const char* Lwf = smem + p.L.wf;
+    const char* Lwf_lo = smem + p.L.wf_lo;
     const float* Lbw1 = reinterpret_cast<const float*>(smem + p.L.bw1);
     const float* Lbb1 = reinterpret_cast<const float*>(smem + p.L.bb1);
     const float* Lbw2 = reinterpret_cast<const float*>(smem + p.L.bw2);
@@ -511,7 +555,17 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             // VGPRs, no scratch, traffic 1.0x, +0.9 % kernel time (profiles/r02_ab/ab2: variant r32, sph8).  The disk
             // kernel has no spills and keeps its fragments in registers (the same change costs it 2 %).  The depth-unrolled
             // 64 x 6 kernels could not hold 5 layers of 64-wide fragments in registers at all: same treatment.
-            if (DOMAIN == BSDFD_DOMAIN_SPHERICAL && ((NM == 2 && NH == 4 && JAC) || (NM == 4 && NH == 6))) asm volatile("");
+            if ((DOMAIN == BSDFD_DOMAIN_SPHERICAL && ((NM == 2 && NH == 4 && JAC) || (NM == 4 && NH == 6))) || (FOLD_L1 && FUSED))
+                asm volatile("");  // (the fused sample+pdf disk kernel carries more live state than PIN below can make room for)
+            // PIN: the folded LO fragments of this step, requested now, consumed ~400 cycles later (first hidden layer)
+            f16x8 pin_f0l[NM], pin_f1l[NM];
+            if (PIN && PREC == BSDFD_PREC_SPLIT3) {
+#pragma unroll
+                for (int mo = 0; mo < NM; ++mo) {
+                    lds_read_b128_async(pin_f0l[mo], Lwf_lo + ((size_t)mo * 64 + lane) * 16);
+                    lds_read_b128_async(pin_f1l[mo], Lwf_lo + (size_t)NM * KC * 64 * 16 + ((size_t)mo * 64 + lane) * 16);
+                }
+            }
             // alpha = float32(t/T) resp. float32(1 - t/T) as torch forms them (python double, then
             // cast); t * (1/T) in fp64 differs from t/T by < 1 ulp(fp64), invisible after the cast.
             float alpha;
@@ -611,6 +665,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 #pragma unroll
                 for (int layer = 0; layer < n_hidden; ++layer) {
                     const bool last = (layer == n_hidden - 1);
+                    // first hidden layer of a disk net: folded tangents (FOLD_L1 above) — split g, not t_0 and t_1
+                    const bool fold = FOLD_L1 && layer == 0 && !last;
                     Frag bh[KC], bl[KC], b0h[KC], b0l[KC], b1h[KC], b1l[KC];
 #pragma unroll
                     for (int m = 0; m < NM; ++m) {
@@ -620,13 +676,15 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                             float gg;
                             silu_grad_scaled(z[m][r], hv[r], gg);
                             if (JAC) {
-                                t0v[r] = zt0[m][r] * gg;
-                                t1v[r] = zt1[m][r] * gg;
+                                t0v[r] = fold ? gg : zt0[m][r] * gg;
+                                if (!fold) t1v[r] = zt1[m][r] * gg;
                             }
                         }
                         const int kc = m >> 1, q0 = 2 * (m & 1);
                         split_pack<SPLIT>(hv, bh[kc].p[q0], bh[kc].p[q0 + 1], bl[kc].p[q0], bl[kc].p[q0 + 1]);
-                        if (JAC) {
+                        if (JAC && fold) {
+                            split_pack<TSPLIT>(t0v, b0h[kc].p[q0], b0h[kc].p[q0 + 1], b0l[kc].p[q0], b0l[kc].p[q0 + 1]);
+                        } else if (JAC) {
                             split_pack<TSPLIT>(t0v, b0h[kc].p[q0], b0h[kc].p[q0 + 1], b0l[kc].p[q0], b0l[kc].p[q0 + 1]);
                             split_pack<TSPLIT>(t1v, b1h[kc].p[q0], b1h[kc].p[q0 + 1], b1l[kc].p[q0], b1l[kc].p[q0 + 1]);
                         }
@@ -642,8 +700,54 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 #pragma unroll
                             for (int mo = 0; mo < NM; ++mo) {
                                 const size_t off = lbase + ((size_t)(mo * KC + kc) * 64 + lane) * 16;
+                                if (PIN) {
+                                    wh[mo] = P_wh[layer < 2 ? layer : 0][mo];
+                                    if (SPLIT) wl[mo] = P_wl[layer < 2 ? layer : 0][mo];
+                                    continue;
+                                }
                                 wh[mo] = *reinterpret_cast<const f16x8*>(Lwh + off);
                                 if (SPLIT) wl[mo] = *reinterpret_cast<const f16x8*>(Lwh_lo + off);
+                            }
+                            if (JAC && fold) {
+                                // tangent accumulators: folded matrices x g (the B fragments of g sit in b0h / b0l); issued
+                                // term-major like the regular layers, so that consecutive MFMAs never share an accumulator
+                                constexpr size_t fstride = (size_t)NM * KC * 64 * 16;
+                                f16x8 f0h[NM], f0l[NM], f1h[NM], f1l[NM];
+#pragma unroll
+                                for (int mo = 0; mo < NM; ++mo) {
+                                    const size_t foff = ((size_t)(mo * KC + kc) * 64 + lane) * 16;
+                                    f0h[mo] = PIN ? P_f0h[mo] : *reinterpret_cast<const f16x8*>(Lwf + foff);
+                                    f1h[mo] = PIN ? P_f1h[mo] : *reinterpret_cast<const f16x8*>(Lwf + fstride + foff);
+                                    if (SPLIT) {
+                                        if (PIN) continue;
+                                        f0l[mo] = *reinterpret_cast<const f16x8*>(Lwf_lo + foff);
+                                        f1l[mo] = *reinterpret_cast<const f16x8*>(Lwf_lo + fstride + foff);
+                                    }
+                                }
+                                if (PIN && SPLIT) {
+                                    lds_wait4(pin_f0l[0], pin_f0l[1 % NM], pin_f1l[0], pin_f1l[1 % NM]);
+#pragma unroll
+                                    for (int mo = 0; mo < NM; ++mo) { f0l[mo] = pin_f0l[mo]; f1l[mo] = pin_f1l[mo]; }
+                                }
+#pragma unroll
+                                for (int mo = 0; mo < NM; ++mo) {
+                                    a[mo] = mfma16(wh[mo], bh[kc].v, a[mo]);
+                                    a0[mo] = mfma16(f0h[mo], b0h[kc].v, a0[mo]);
+                                    a1[mo] = mfma16(f1h[mo], b0h[kc].v, a1[mo]);
+                                }
+                                if (SPLIT) {
+#pragma unroll
+                                    for (int mo = 0; mo < NM; ++mo) {
+                                        a[mo] = mfma16(wh[mo], bl[kc].v, a[mo]);
+                                        if (TSPLIT) { a0[mo] = mfma16(f0h[mo], b0l[kc].v, a0[mo]); a1[mo] = mfma16(f1h[mo], b0l[kc].v, a1[mo]); }
+                                    }
+#pragma unroll
+                                    for (int mo = 0; mo < NM; ++mo) {
+                                        a[mo] = mfma16(wl[mo], bh[kc].v, a[mo]);
+                                        if (TWLO) { a0[mo] = mfma16(f0l[mo], b0h[kc].v, a0[mo]); a1[mo] = mfma16(f1l[mo], b0h[kc].v, a1[mo]); }
+                                    }
+                                }
+                                continue;
                             }
 #pragma unroll
                             for (int mo = 0; mo < NM; ++mo) {
@@ -671,7 +775,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                         f32x4 e = zero4, e0 = zero4, e1 = zero4;
 #pragma unroll
                         for (int kc = 0; kc < KC; ++kc) {
-                            const f16x8 wo = *reinterpret_cast<const f16x8*>(Lwo + ((size_t)kc * 64 + lane) * 16);
+                            const f16x8 wo = PIN ? P_wo : *reinterpret_cast<const f16x8*>(Lwo + ((size_t)kc * 64 + lane) * 16);
                             e = mfma16(wo, bh[kc].v, e);
                             if (JAC) { e0 = mfma16(wo, b0h[kc].v, e0); e1 = mfma16(wo, b1h[kc].v, e1); }
                             if (SPLIT) {
@@ -829,6 +933,15 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
         if (prec == BSDFD_PREC_SPLIT3) off += (NH - 1) * NM * KC * 64 * 16;
         L.wo = off; off += KC * 64 * 16;
     }
+    L.wf = L.wf_lo = 0;
+    // folded layer-1 tangent matrices W2 diag(W1[:, i]), i = 0, 1, of the disk nets (FOLD_L1 in the kernel)
+    const bool fold = d.domain == BSDFD_DOMAIN_DISK && prec != BSDFD_PREC_F32 && NH >= 2 && NM == 2;
+    const int NFOLD = 2;
+    if (fold) {
+        L.wf = off; off += NFOLD * NM * KC * 64 * 16;
+        L.wf_lo = off;
+        if (prec == BSDFD_PREC_SPLIT3) off += NFOLD * NM * KC * 64 * 16;
+    }
     L.bw1 = off; off += (BASE_PE_BANDS + 1) * 64 * 4;
     L.bb1 = off; off += 64 * 16;
     L.bw2 = off; off += 64 * 16;
@@ -887,6 +1000,20 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
                             H(L.wh)[idx] = f32_to_f16_bits(w);
                             if (prec == BSDFD_PREC_SPLIT3) H(L.wh_lo)[idx] = f32_to_f16_bits(w - hi);
                         }
+        if (fold)
+            for (int i = 0; i < NFOLD; ++i)
+                for (int mo = 0; mo < NM; ++mo)
+                    for (int kc = 0; kc < KC; ++kc)
+                        for (int l = 0; l < 64; ++l)
+                            for (int j = 0; j < 8; ++j) {
+                                const int k = 16 * (2 * kc + (j >> 2)) + 4 * (l >> 4) + (j & 3);
+                                // (W2 diag(w_i))[unit][k] in double; w_i = the scaled layer-1 column (what zt{0,1}c hold)
+                                const double v = (double)d.w_hidden[((size_t)16 * mo + (l & 15)) * W + k] * (double)d.w_in[(size_t)k * IN + i];
+                                const size_t idx = ((((size_t)i * NM + mo) * KC + kc) * 64 + l) * 8 + j;
+                                const float hi = f16_round((float)v);
+                                H(L.wf)[idx] = f32_to_f16_bits((float)v);
+                                if (prec == BSDFD_PREC_SPLIT3) H(L.wf_lo)[idx] = f32_to_f16_bits((float)(v - (double)hi));
+                            }
         for (int kc = 0; kc < KC; ++kc)
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {

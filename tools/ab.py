@@ -105,6 +105,15 @@ def main():
         plug("disk8", "aniso_miro_7_rgb", "disk", None, 1 << 20, 8)
     if "disk4" in only:
         plug("disk4", "aniso_miro_7_rgb", "disk", None, 1 << 20, 4)
+    if "fused4" in only:  # sample(wi) + pdf(wi, wl) in one launch (the renderer's call pattern), disk T = 4
+        fw = W.load(W.shipped_path("aniso_miro_7_rgb", "disk"))
+        smp = FlowSampler(fw)
+        n = 1 << 20
+        wi, wl = bench.make_wi("disk", n, 1234, dev), bench.make_wi("disk", n, 99, dev)
+        settle(smp, wi, 4)
+        ms, mn = kernel_ms(smp, lambda: smp.plugin_sample_pdf(wi, wl, None, T=4, seed=3), a.reps)
+        out["fused4"] = {"ms": ms, "min": mn}
+        smp.close()
     if "sph8" in only:
         plug("sph8", "aniso_miro_7_rgb", "spherical", None, 1 << 22, 8)
     if "cplx8" in only:

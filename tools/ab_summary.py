@@ -5,7 +5,7 @@ import numpy as np
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.strip().startswith("{")]
 tags = list(dict.fromkeys(r["tag"] for r in rows))
 keys = [("disk8", "sample_ms"), ("disk8", "pdf_ms"), ("disk4", "sample_ms"), ("disk4", "pdf_ms"), ("sph8", "sample_ms"),
-        ("sph8", "pdf_ms"), ("cplx8", "sample_ms"), ("cplx8", "pdf_ms"), ("teacher", "ms")]
+        ("sph8", "pdf_ms"), ("cplx8", "sample_ms"), ("cplx8", "pdf_ms"), ("teacher", "ms"), ("fused4", "ms")]
 med = collections.defaultdict(dict)
 for t in tags:
     for w, k in keys:
