@@ -46,6 +46,7 @@ WORKLOADS = {
     "teacher_64x6_4Mi_T128": ("teacher", "aniso_miro_7_rgb", "spherical", 1 << 22, 128),
 }
 SECONDARY = ("disk_1Mi_T4", "spherical_16Mi_T8", "mixed_16Mi", "teacher_64x6_4Mi_T128")
+USE_CONTEXT = os.environ.get("BSDFD_BENCH_CONTEXT", "1") != "0"  # --context off: plain sample() / pdf() calls
 
 
 def make_wi(domain, n, seed, device):
@@ -215,12 +216,15 @@ class SingleMaterial:
         self.query_launches_per_pass = 2 * n
         self.precision = self.smp.precision
         self.last = 0
+        # per-query context (include/bsdfd.h, bsdfd_context_bytes): sample() writes what depends on wi alone, pdf() of
+        # the same wavefront reads it instead of recomputing the prologue; bit-identical results (tests/test_gpu_parity.py)
+        self.ctx = self.smp.new_context(n) if USE_CONTEXT else None
 
     def run_pass(self, k):
         b = k & 1
         self.smp.plugin_sample(self.wi, None, T=self.T, variant=self.variant, seed=1000 + k, offset=self.rank * self.n_local,
-                               out=(self.wo[b], self.pdf_s[b]))
-        self.smp.plugin_pdf(self.wi, self.wo[b], T=self.T, variant=self.variant, out=self.pdf_p[b])
+                               out=(self.wo[b], self.pdf_s[b]), ctx_out=self.ctx)
+        self.smp.plugin_pdf(self.wi, self.wo[b], T=self.T, variant=self.variant, out=self.pdf_p[b], ctx_in=self.ctx)
         self.last = b
 
     def result(self):
@@ -235,7 +239,8 @@ class SingleMaterial:
 
     def config(self):
         return {"material": self.material, "domain": self.domain, "euler_steps": self.T,
-                "api": "plugin-level sample()+pdf() (warp + guards fused), in-kernel Philox RNG"}
+                "api": "plugin-level sample()+pdf() (warp + guards fused), in-kernel Philox RNG",
+                "per_query_context": self.ctx is not None}
 
 
 class MixedMaterials:
@@ -259,6 +264,7 @@ class MixedMaterials:
         self.query_launches_per_pass = 2 * self.n_local
         self.precision = self.tab.samplers[0].precision
         self.out = None
+        self.ctx = {} if USE_CONTEXT else None  # per-query contexts of the wavefront's runs (MaterialTable.sample(ctx=))
 
     def run_pass(self, k):
         # one bucketing and ONE gather of the inputs per wavefront; sample() and pdf() run on the bucket-ordered arrays;
@@ -266,8 +272,8 @@ class MixedMaterials:
         tab = self.tab
         plan = tab.bucket(self.ids)
         wi_b = tab.gather(plan, self.wi)
-        wo_b, pdf_b = tab.sample(plan, wi_b, seed=1000 + k, offset=self.rank * self.n_local, bucketed=True)
-        p_b = tab.pdf(plan, wi_b, wo_b, bucketed=True)
+        wo_b, pdf_b = tab.sample(plan, wi_b, seed=1000 + k, offset=self.rank * self.n_local, bucketed=True, ctx=self.ctx)
+        p_b = tab.pdf(plan, wi_b, wo_b, bucketed=True, ctx=self.ctx)
         self.out = tab.scatter(plan, wo_b, pdf_b, p_b)
 
     def result(self):
@@ -284,7 +290,7 @@ class MixedMaterials:
         return {"materials": len(self.tab), "domain": "27 disk + 25 spherical", "euler_steps": "4 (disk) / 8 (spherical)",
                 "api": "MaterialTable: bucket-by-material (native counting sort), one gather of wi, segmented plugin "
                        "sample()/pdf() launches on the bucket-ordered arrays, one scatter of (wo, pdf, pdf) back to lane order "
-                       "— all inside the step"}
+                       "— all inside the step", "per_query_context": self.ctx is not None}
 
 
 class Teacher:
@@ -687,12 +693,18 @@ def main():
                          "modes are timed too and reported under `multi_gpu`")
     ap.add_argument("--passes-per-step", type=int, default=0,
                     help="wavefronts per step (0 = sized at setup so that the timed region lasts >= 0.5 s)")
+    ap.add_argument("--context", default=None, choices=["on", "off"],
+                    help="per-query context hand-over from sample() to pdf() of the same wavefront (default on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="setup: keep the GPU busy with the hot path for this long before the W warm-up steps, so "
                          "that the timed region does not start on an idle-clocked chip")
     a = ap.parse_args()
+    if a.context is not None:  # also reaches the self-launched ranks (children inherit the environment)
+        global USE_CONTEXT
+        USE_CONTEXT = a.context == "on"
+        os.environ["BSDFD_BENCH_CONTEXT"] = "1" if USE_CONTEXT else "0"
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if a.gpus > 1 and "RANK" not in os.environ:

@@ -29,6 +29,8 @@ EXPORTS = (
     "bsdfd_flops_per_query", "bsdfd_network_sampling", "bsdfd_network_pdf",
     "bsdfd_plugin_sample", "bsdfd_plugin_pdf", "bsdfd_plugin_sample_pdf", "bsdfd_plugin_sample_multi", "bsdfd_plugin_pdf_multi",
     "bsdfd_plugin_sample_pdf_multi",
+    "bsdfd_context_bytes", "bsdfd_plugin_sample_ctx", "bsdfd_plugin_pdf_ctx", "bsdfd_plugin_sample_multi_ctx",
+    "bsdfd_plugin_pdf_multi_ctx",
     "bsdfd_flow_samples_only", "bsdfd_wf_primary", "bsdfd_wf_shade",
     "bsdfd_positional_encoding", "bsdfd_bucket_workspace_bytes", "bsdfd_bucket_by_material",
     "bsdfd_gather_lanes", "bsdfd_scatter_lanes",
@@ -111,6 +113,12 @@ def lib():
     L.bsdfd_plugin_sample_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, u64, u64, i32, fp, fp, vp]
     L.bsdfd_plugin_sample_pdf_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, fp, u64, u64, i32, fp, fp, fp, vp]
     L.bsdfd_plugin_pdf_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, i32, fp, vp]
+    L.bsdfd_context_bytes.argtypes = [vp, i64, i32]
+    L.bsdfd_context_bytes.restype = i64
+    L.bsdfd_plugin_sample_ctx.argtypes = [vp, i32, fp, fp, u64, u64, i64, i32, fp, fp, fp, vp]
+    L.bsdfd_plugin_pdf_ctx.argtypes = [vp, i32, fp, fp, i64, i32, fp, fp, vp]
+    L.bsdfd_plugin_sample_multi_ctx.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, u64, u64, i32, fp, fp, fp, vp]
+    L.bsdfd_plugin_pdf_multi_ctx.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, i32, fp, fp, vp]
     L.bsdfd_flow_samples_only.argtypes = [vp, fp, fp, i64, i32, fp, vp]
     L.bsdfd_wf_primary.argtypes = [C.POINTER(WfScene), i32, i32, i32, u64, u64, fp, fp, fp, fp, fp, vp]
     L.bsdfd_wf_shade.argtypes = [C.POINTER(WfScene), fp, i32, i32, i32, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp]

@@ -86,6 +86,11 @@ struct KParams {
     // material's weight image.  nseg == 0: ordinary single-material launch over [0, N).
     const float* in_c;   // OP_SAMPLE_PDF: wl [N,3], the direction whose pdf is asked
     float* out_pdf2;     // OP_SAMPLE_PDF: pdf(wi, wl) [N]
+    // per-query context (everything derived from wi alone: conditioning term of layer 1 + base-net outputs), see
+    // bsdfd_context_bytes: written by a sample launch (ctx_out), read instead of recomputed by a pdf launch (ctx_in)
+    float* ctx_out;
+    const float* ctx_in;
+    int seg_base;    // segmented launches: buckets served by EARLIER launches of the same call (context slot numbering)
     int chunk_log2;  // a wave takes 2^chunk_log2 consecutive-ish tiles per chunk (see the tile map in the kernel)
     int nseg;
     struct Seg {
@@ -279,8 +284,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
     const char* img = p.img;
     long long q_begin = 0, q_end = p.N;
     int blk = blockIdx.x, nblk = gridDim.x, cl = p.chunk_log2;
+    int sidx = 0;
     if (p.nseg > 0) {
-        int sidx = 0;
         for (int i = 1; i < p.nseg; ++i)
             if ((int)blockIdx.x >= p.seg[i].blk_begin) sidx = i;
         img = p.seg[sidx].img;
@@ -390,9 +395,12 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
         const long long qi = valid ? qi_raw : q_end - 1;
 
         // ---------------- inputs: condition (y0,y1) and, for pdf, the outgoing point -------------
-        float y0, y1, wi_z = 1.0f;
+        float y0 = 0.f, y1 = 0.f, wi_z = 1.0f;
         float xs0 = 0.f, xs1 = 0.f, wo_z = 1.0f, wo_sin = 1.0f;  // pdf: the point the reverse flow starts from
         float xi0 = 0.f, xi1 = 0.f;                              // sample: injected x0 (if any)
+        // per-query context: a pdf launch that is handed the context a sample launch wrote for the SAME wi array skips
+        // everything below that depends on wi alone (cart_to_spher(wi), encoding, conditioning term, base net)
+        const bool have_ctx = !FUSED && p.ctx_in != nullptr;
         if (p.io == IO_OPERATOR) {
             const float2 c2 = reinterpret_cast<const float2*>(p.in_a)[qi];
             y0 = c2.x; y1 = c2.y;
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             wi_z = wz;
             if (DOMAIN == BSDFD_DOMAIN_DISK) {
                 y0 = wx; y1 = wy;  // rendering/brdf_measured_disk.py:66-67
-            } else {               // cart_to_spher, rendering/brdf_measured_spherical.py:35-39
+            } else if (!have_ctx) {  // cart_to_spher, rendering/brdf_measured_spherical.py:35-39
                 const float r = sqrtf(wx * wx + wy * wy + wz * wz);
                 y0 = acosf(wz / (r + 1e-8f));
                 y1 = atan2f(wy, wx);
@@ -429,6 +437,18 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             }
         }
 
+        f32x4 cacc[NM];
+        f32x4 bo;
+        // context slot of this tile: tiles of one bucket start 16 queries apart and a later bucket starts at or after the
+        // end of the previous one, so floor(first query / 16) + bucket index is unique (bsdfd_context_bytes sizes for it)
+        constexpr long long CTX_V4 = NM * 64 + 16;  // f32x4 per tile: cacc[NM] per lane + bo per query
+        const long long ctx_slot = ((q_begin + tile * 16) >> 4) + p.seg_base + sidx;
+        if (have_ctx) {
+            const f32x4* c = reinterpret_cast<const f32x4*>(p.ctx_in) + ctx_slot * CTX_V4;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) cacc[m] = c[m * 64 + lane];
+            bo = c[NM * 64 + q];
+        } else {
         // ---------------- positional encoding, distributed over the 4 lanes of a query -----------
         // lane g needs fn(2^b y_d) for dim d = g&1, fn = g>>1 ? cos : sin, b = 0..4: slab b of the K=4
         // contraction is [sin(2^b y0), sin(2^b y1), cos(2^b y0), cos(2^b y1)] = PE block b.  Lanes g and
@@ -464,8 +484,6 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 
         // conditioning part of layer 1 (constant across the Euler steps) and the base-density net
         // PE_3 -> 16 (SiLU) -> 4, once per query
-        f32x4 cacc[NM];
-        f32x4 bo;
         // c = W1[:, PE] PE(omega_i): exact fp32 MFMA chains (K = 4 slabs) in EVERY precision mode — this
         // term enters z1 of all T steps, so its rounding error is systematic: an fp16-split version
         // saved ~12 us per 1 Mi queries but raised the p99 pdf error from 1.8e-5 to 2.9e-5 (the MFMA's
@@ -491,6 +509,13 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 #pragma unroll
             for (int r = 0; r < 4; ++r) bo = mfma4(w2[r], silu(bz[r]), bo);
         }
+        if (!FUSED && p.ctx_out != nullptr) {  // one 1-KiB store per accumulator and wave, 16 B per query for bo
+            f32x4* c = reinterpret_cast<f32x4*>(p.ctx_out) + ctx_slot * CTX_V4;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) c[m * 64 + lane] = cacc[m];
+            if (g == 0) c[NM * 64 + q] = bo;
+        }
+        }  // !have_ctx
         // bo = (loc0, loc1, ls0, ls1) disk | (loc, log_scale, mu, kappa_raw) spherical
         float kappa = 0.0f;
         if (DOMAIN == BSDFD_DOMAIN_SPHERICAL) kappa = softplus(bo[3]) + 1e-3f;
@@ -1078,9 +1103,15 @@ struct SegHost {
     long long q_begin, q_end;
 };
 
+struct CtxArg {  // per-query context buffers of a call (bsdfd_context_bytes) and the bucket numbering base
+    float* out = nullptr;
+    const float* in = nullptr;
+    int seg_base = 0;
+};
+
 int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, uint64_t seed, uint64_t offset,
         int64_t N, int T, float* out_x, float* out_pdf, void* stream, const std::vector<SegHost>* segs = nullptr,
-        const float* in_c = nullptr, float* out_pdf2 = nullptr) {
+        const float* in_c = nullptr, float* out_pdf2 = nullptr, CtxArg ctx = CtxArg()) {
     if (!h) return fail(BSDFD_EINVAL, "null handle");
     if (N < 0) return fail(BSDFD_EINVAL, "N must be >= 0");
     if (T < 1 || T > 4096) return fail(BSDFD_EINVAL, "T must be in [1, 4096]");
@@ -1094,6 +1125,10 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     if (op != OP_SAMPLES_ONLY && !out_pdf) return fail(BSDFD_EINVAL, "null pdf output pointer");
     if (io == IO_PLUGIN_FULLSPHERE && h->domain != BSDFD_DOMAIN_SPHERICAL)
         return fail(BSDFD_EINVAL, "the full-sphere plugin variant needs a spherical-domain handle");
+    if ((ctx.out && op != OP_SAMPLE) || (ctx.in && op != OP_PDF))
+        return fail(BSDFD_EINVAL, "a per-query context is written by sample calls and read by pdf calls only");
+    if ((reinterpret_cast<uintptr_t>(ctx.out) | reinterpret_cast<uintptr_t>(ctx.in)) & 15u)
+        return fail(BSDFD_EINVAL, "the per-query context buffer must be 16-byte aligned");
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     if (dev != h->device) return fail(BSDFD_EINVAL, "handle was created on device " + std::to_string(h->device) +
@@ -1105,6 +1140,7 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     kp.N = N; kp.T = T; kp.n_hidden = h->n_hidden; kp.op = op; kp.io = io; kp.seed = seed; kp.offset = offset;
     kp.nseg = 0;
     kp.chunk_log2 = 3;
+    kp.ctx_out = ctx.out; kp.ctx_in = ctx.in; kp.seg_base = ctx.seg_base;
 
     const int NM = h->width / 16;
     const int threads = threads_for(NM);
@@ -1196,7 +1232,7 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
 // multi-material launch: all handles must share the kernel signature (domain, width, depth, precision)
 int run_multi(const bsdfd_handle* hs, int n, const int64_t* seg_end, int op, int io, const float* in_a,
               const float* in_b, uint64_t seed, uint64_t offset, int T, float* out_x, float* out_pdf, void* stream,
-              const float* in_c = nullptr, float* out_pdf2 = nullptr) {
+              const float* in_c = nullptr, float* out_pdf2 = nullptr, CtxArg ctx = CtxArg()) {
     if (!hs || !seg_end || n < 1) return fail(BSDFD_EINVAL, "need at least one handle and its segment end");
     for (int i = 0; i < n; ++i) {
         if (!hs[i]) return fail(BSDFD_EINVAL, "null handle in the table");
@@ -1215,7 +1251,8 @@ int run_multi(const bsdfd_handle* hs, int n, const int64_t* seg_end, int op, int
         const long long b = i ? seg_end[i - 1] : 0, e = seg_end[i];
         if (e > b) segs.push_back({hs[i], b, e});
         if ((int)segs.size() == MAX_SEG || (i == n - 1 && !segs.empty())) {
-            rc = run(segs[0].h, op, io, in_a, in_b, seed, offset, N, T, out_x, out_pdf, stream, &segs, in_c, out_pdf2);
+            rc = run(segs[0].h, op, io, in_a, in_b, seed, offset, N, T, out_x, out_pdf, stream, &segs, in_c, out_pdf2, ctx);
+            ctx.seg_base += (int)segs.size();
             segs.clear();
         }
     }
@@ -1382,6 +1419,55 @@ int bsdfd_plugin_pdf(bsdfd_handle h, int32_t variant, const float* wi, const flo
         return fail(BSDFD_EINVAL, "unknown plugin variant");
     return run(h, OP_PDF, variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, wo, 0, 0, N, T,
                nullptr, pdf_sa, stream);
+}
+
+int64_t bsdfd_context_bytes(bsdfd_handle h, int64_t N, int32_t n_segments) {
+    if (!h || N < 0 || n_segments < 1) return -1;
+    const int64_t per_tile = ((int64_t)(h->width / 16) * 64 + 16) * 16;  // cacc[NM] per lane + bo per query, 16 B each
+    return ((N + 15) / 16 + n_segments) * per_tile;
+}
+
+int bsdfd_plugin_sample_ctx(bsdfd_handle h, int32_t variant, const float* wi, const float* x0, uint64_t seed,
+                            uint64_t offset, int64_t N, int32_t T, float* wo, float* pdf_sa, void* ctx_out, void* stream) {
+    if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
+        return fail(BSDFD_EINVAL, "unknown plugin variant");
+    CtxArg c;
+    c.out = static_cast<float*>(ctx_out);
+    return run(h, OP_SAMPLE, variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, x0, seed, offset,
+               N, T, wo, pdf_sa, stream, nullptr, nullptr, nullptr, c);
+}
+
+int bsdfd_plugin_pdf_ctx(bsdfd_handle h, int32_t variant, const float* wi, const float* wo, int64_t N, int32_t T,
+                         float* pdf_sa, const void* ctx_in, void* stream) {
+    if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
+        return fail(BSDFD_EINVAL, "unknown plugin variant");
+    CtxArg c;
+    c.in = static_cast<const float*>(ctx_in);
+    return run(h, OP_PDF, variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, wo, 0, 0, N, T,
+               nullptr, pdf_sa, stream, nullptr, nullptr, nullptr, c);
+}
+
+int bsdfd_plugin_sample_multi_ctx(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end, int32_t variant,
+                                  const float* wi, const float* x0, uint64_t seed, uint64_t offset, int32_t T, float* wo,
+                                  float* pdf_sa, void* ctx_out, void* stream) {
+    if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
+        return fail(BSDFD_EINVAL, "unknown plugin variant");
+    CtxArg c;
+    c.out = static_cast<float*>(ctx_out);
+    return run_multi(handles, n_handles, seg_end, OP_SAMPLE,
+                     variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, x0, seed, offset, T, wo,
+                     pdf_sa, stream, nullptr, nullptr, c);
+}
+
+int bsdfd_plugin_pdf_multi_ctx(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end, int32_t variant,
+                               const float* wi, const float* wo, int32_t T, float* pdf_sa, const void* ctx_in, void* stream) {
+    if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
+        return fail(BSDFD_EINVAL, "unknown plugin variant");
+    CtxArg c;
+    c.in = static_cast<const float*>(ctx_in);
+    return run_multi(handles, n_handles, seg_end, OP_PDF,
+                     variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, wo, 0, 0, T, nullptr,
+                     pdf_sa, stream, nullptr, nullptr, c);
 }
 
 int bsdfd_plugin_sample_pdf(bsdfd_handle h, int32_t variant, const float* wi, const float* x0, const float* wl,

@@ -213,6 +213,51 @@ void plugin_pdf_out(int64_t h, int64_t variant, const Tensor& wi, const Tensor& 
                         pdf.data_ptr<float>(), L.stream));
 }
 
+// ---- per-query context (bsdfd_context_bytes): sample() writes it, pdf() for the same wi reads it ------
+void* ctx_ptr(const Tensor& ctx, int64_t h, int64_t n, const at::Device& dev) {
+    const int64_t need = bsdfd_context_bytes(as_handle(h), n, 1);
+    TORCH_CHECK(need >= 0, "bsdfd_context_bytes: bad arguments");
+    TORCH_CHECK(ctx.device() == dev && ctx.scalar_type() == at::kFloat && ctx.dim() == 1 && ctx.is_contiguous() &&
+                    ctx.numel() * 4 >= need && reinterpret_cast<uintptr_t>(ctx.data_ptr()) % 16 == 0,
+                "context must be a contiguous, 16-byte aligned float32 tensor of >= ", need / 4, " elements on ", dev);
+    return ctx.data_ptr();
+}
+
+int64_t context_floats(int64_t h, int64_t n, int64_t n_segments) {
+    const int64_t b = bsdfd_context_bytes(as_handle(h), n, static_cast<int32_t>(n_segments));
+    TORCH_CHECK(b >= 0, "bsdfd_context_bytes: bad arguments");
+    return b / 4;
+}
+
+void plugin_sample_ctx_out(int64_t h, int64_t variant, const Tensor& wi, const std::optional<Tensor>& x0, int64_t seed,
+                           int64_t offset, int64_t T, Tensor wo, Tensor pdf, Tensor ctx) {
+    const at::Device dev = wi.device();
+    const float* wip = in2d(wi, 3, "wi", dev);
+    const int64_t n = wi.size(0);
+    const float* x0p = opt2d(x0, 2, "x0", dev, n);
+    in2d(wo, 3, "wo (out)", dev, n);
+    TORCH_CHECK(pdf.device() == dev && pdf.scalar_type() == at::kFloat && pdf.dim() == 1 && pdf.size(0) == n && pdf.is_contiguous(),
+                "pdf (out) must be a contiguous float32 tensor of shape [", n, "] on ", dev);
+    void* c = ctx_ptr(ctx, h, n, dev);
+    Launch L(dev);
+    ok(bsdfd_plugin_sample_ctx(as_handle(h), static_cast<int32_t>(variant), wip, x0p, static_cast<uint64_t>(seed),
+                               static_cast<uint64_t>(offset), n, static_cast<int32_t>(T), wo.data_ptr<float>(),
+                               pdf.data_ptr<float>(), c, L.stream));
+}
+
+void plugin_pdf_ctx_out(int64_t h, int64_t variant, const Tensor& wi, const Tensor& wo, int64_t T, Tensor pdf, const Tensor& ctx) {
+    const at::Device dev = wi.device();
+    const float* wip = in2d(wi, 3, "wi", dev);
+    const int64_t n = wi.size(0);
+    const float* wop = in2d(wo, 3, "wo", dev, n);
+    TORCH_CHECK(pdf.device() == dev && pdf.scalar_type() == at::kFloat && pdf.dim() == 1 && pdf.size(0) == n && pdf.is_contiguous(),
+                "pdf (out) must be a contiguous float32 tensor of shape [", n, "] on ", dev);
+    const void* c = ctx_ptr(ctx, h, n, dev);
+    Launch L(dev);
+    ok(bsdfd_plugin_pdf_ctx(as_handle(h), static_cast<int32_t>(variant), wip, wop, n, static_cast<int32_t>(T),
+                            pdf.data_ptr<float>(), c, L.stream));
+}
+
 }  // namespace
 
 TORCH_LIBRARY(bsdfd, m) {
@@ -231,4 +276,8 @@ TORCH_LIBRARY(bsdfd, m) {
     m.def("plugin_sample_out(int handle, int variant, Tensor wi, Tensor? x0, int seed, int offset, int T, Tensor(a!) wo, Tensor(b!) pdf) -> ()",
           &plugin_sample_out);
     m.def("plugin_pdf_out(int handle, int variant, Tensor wi, Tensor wo, int T, Tensor(a!) pdf) -> ()", &plugin_pdf_out);
+    m.def("context_floats(int handle, int n, int n_segments) -> int", &context_floats);
+    m.def("plugin_sample_ctx_out(int handle, int variant, Tensor wi, Tensor? x0, int seed, int offset, int T, Tensor(a!) wo, "
+          "Tensor(b!) pdf, Tensor(c!) ctx) -> ()", &plugin_sample_ctx_out);
+    m.def("plugin_pdf_ctx_out(int handle, int variant, Tensor wi, Tensor wo, int T, Tensor(a!) pdf, Tensor ctx) -> ()", &plugin_pdf_ctx_out);
 }

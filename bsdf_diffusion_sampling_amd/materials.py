@@ -71,8 +71,13 @@ class MaterialTable:
             groups.setdefault(key, []).append(m)
         return groups
 
-    def _multi(self, which, members, seg_end_all, T, variant, wi_s, aux_s, seed, offset, out_wo, out_pdf):
-        """Segmented launch(es) for the materials `members` of one kernel signature.  The bucketed arrays
+    def _multi(self, which, members, seg_end_all, T, variant, wi_s, aux_s, seed, offset, out_wo, out_pdf, ctx=None,
+               gkey=None):
+        """``ctx`` (a dict, or None): per-query contexts (include/bsdfd.h, bsdfd_context_bytes) of the runs of this
+        wavefront — a "sample" call creates and fills one buffer per (kernel signature, run), a "pdf" call on the same
+        bucketed ``wi`` reads them instead of recomputing the per-query prologue.
+
+        Segmented launch(es) for the materials `members` of one kernel signature.  The bucketed arrays
         are ordered by material id, so a group's buckets may be interleaved with other groups'; each
         maximal run of ADJACENT buckets becomes one `bsdfd_plugin_*_multi` call on the run's row range
         (pointers advanced to the run's first row, Philox offset advanced by the same amount)."""
@@ -90,7 +95,31 @@ class MaterialTable:
             arr_e = (C.c_int64 * k)(*[e - base for e in run_end])
             off_rows = base
             wi_p = C.c_void_p(wi_s.data_ptr() + off_rows * 12)
-            if which == "sample":
+            cbuf = None
+            if ctx is not None and which in ("sample", "pdf"):
+                ckey = (gkey, base, tuple(run_end))
+                if which == "sample":
+                    nbytes = int(L.bsdfd_context_bytes(run_h[0], run_end[-1] - base, k))
+                    cbuf = ctx.get(ckey)
+                    if cbuf is None or cbuf.numel() * 4 < nbytes or cbuf.device != wi_s.device:
+                        cbuf = ctx[ckey] = torch.empty((nbytes // 4,), dtype=torch.float32, device=wi_s.device)
+                else:
+                    cbuf = ctx.get(ckey)
+                    if cbuf is None:
+                        raise ValueError("pdf(ctx=...) needs the context a sample(ctx=...) call of the SAME bucketed "
+                                         "wavefront filled")
+            if which == "sample" and cbuf is not None:
+                x0_p = None if aux_s is None else C.c_void_p(aux_s.data_ptr() + off_rows * 8)
+                r = L.bsdfd_plugin_sample_multi_ctx(arr_h, k, arr_e, variant, wi_p, x0_p, seed, offset + off_rows, T,
+                                                    C.c_void_p(out_wo.data_ptr() + off_rows * 12),
+                                                    C.c_void_p(out_pdf.data_ptr() + off_rows * 4),
+                                                    C.c_void_p(cbuf.data_ptr()), stream)
+            elif which == "pdf" and cbuf is not None:
+                r = L.bsdfd_plugin_pdf_multi_ctx(arr_h, k, arr_e, variant, wi_p,
+                                                 C.c_void_p(aux_s.data_ptr() + off_rows * 12), T,
+                                                 C.c_void_p(out_pdf.data_ptr() + off_rows * 4),
+                                                 C.c_void_p(cbuf.data_ptr()), stream)
+            elif which == "sample":
                 x0_p = None if aux_s is None else C.c_void_p(aux_s.data_ptr() + off_rows * 8)
                 r = L.bsdfd_plugin_sample_multi(arr_h, k, arr_e, variant, wi_p, x0_p, seed, offset + off_rows, T,
                                                 C.c_void_p(out_wo.data_ptr() + off_rows * 12),
@@ -214,8 +243,10 @@ class MaterialTable:
 
     def sample(self, material_id: torch.Tensor, wi: torch.Tensor, seed: int = 0, offset: int = 0,
                T: Optional[int] = None, x0: Optional[torch.Tensor] = None, segmented: bool = True,
-               bucketed: bool = False):
+               bucketed: bool = False, ctx: Optional[dict] = None):
         """wi [N,3], material_id [N] -> (wo [N,3], pdf_sa [N]) in the callers' order.
+        ``ctx``: a dict this call fills with the wavefront's per-query contexts; hand the same dict (and the same
+        plan and ``wi``) to ``pdf(..., ctx=)`` and it skips the per-query prologue (identical results).
         The Philox counter of a query is ``offset + its row in the bucketed (sorted-by-material)
         array``, identical for the segmented and the per-bucket path.  ``bucketed=True``: ``material_id`` is a
         plan, ``wi`` / ``x0`` are already in bucket order (``gather(plan, wi)``) and the results stay in it."""
@@ -236,7 +267,7 @@ class MaterialTable:
             with torch.cuda.device(wi.device):
                 for (dom, w, nh, prec, Tm, var), members in self._groups().items():
                     self._multi("sample", members, seg_end, Tm if T is None else T, var, wi_s, x0_s, seed, offset,
-                                wo_s, pdf_s)
+                                wo_s, pdf_s, ctx=ctx, gkey=(dom, w, nh, prec, var))
         else:
             lo = 0
             for m, n in enumerate(counts):
@@ -288,7 +319,7 @@ class MaterialTable:
         return wo, po, pl
 
     def pdf(self, material_id: torch.Tensor, wi: torch.Tensor, wo: torch.Tensor, T: Optional[int] = None,
-            segmented: bool = True, bucketed: bool = False):
+            segmented: bool = True, bucketed: bool = False, ctx: Optional[dict] = None):
         wi = self._chk_in(wi, 3, "wi")
         wo = self._chk_in(wo, 3, "wo", wi.shape[0])
         if bucketed:
@@ -303,7 +334,8 @@ class MaterialTable:
         if segmented:
             with torch.cuda.device(wi.device):
                 for (dom, w, nh, prec, Tm, var), members in self._groups().items():
-                    self._multi("pdf", members, seg_end, Tm if T is None else T, var, wi_s, wo_s, 0, 0, None, pdf_s)
+                    self._multi("pdf", members, seg_end, Tm if T is None else T, var, wi_s, wo_s, 0, 0, None, pdf_s,
+                                ctx=ctx, gkey=(dom, w, nh, prec, var))
         else:
             lo = 0
             for m, n in enumerate(counts):

@@ -89,6 +89,12 @@ class NeuralBSDFCore:
         self.albedo = torch.tensor(get("albedo", [1.0, 1.0, 1.0]), dtype=torch.float32)
         fw = self._load_weights(get("weights", None), get("checkpoint_dir", None))
         self.sampler = FlowSampler(fw, precision=self.precision)
+        # per-query context of the last sample() call (include/bsdfd.h, bsdfd_context_bytes): a renderer calls
+        # sample(si) and then pdf(si, wl) for the same intersections (rendering/brdf_measured_disk.py:59,112), so pdf()
+        # may skip what depends on si.wi alone.  Keyed on the identity of the wi tensor; 144 B per query, capped.
+        self.context_cache = bool(get("context_cache", True))
+        self.context_cache_max_bytes = int(get("context_cache_max_bytes", 4 << 30))
+        self._ctx = None      # (data_ptr, _version, n, device, buffer)
 
     # -- weight discovery ------------------------------------------------
     def _material_name(self) -> str:
@@ -122,10 +128,45 @@ class NeuralBSDFCore:
         the firefly rule is separate (``apply_firefly_clamp``) because it needs eval()."""
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
-        return self.sampler.plugin_sample(wi, x0, T=self.T, variant=self.VARIANT, seed=seed, offset=offset)
+        return self.sampler.plugin_sample(wi, x0, T=self.T, variant=self.VARIANT, seed=seed, offset=offset,
+                                          ctx_out=self._ctx_for_sample(wi))
 
     def pdf_t(self, wi: torch.Tensor, wo: torch.Tensor) -> torch.Tensor:
-        return self.sampler.plugin_pdf(wi, wo, T=self.T, variant=self.VARIANT)
+        return self.sampler.plugin_pdf(wi, wo, T=self.T, variant=self.VARIANT, ctx_in=self._ctx_for_pdf(wi))
+
+    # -- context cache -----------------------------------------------------
+    @staticmethod
+    def _wi_key(wi: torch.Tensor):
+        return (wi.data_ptr(), wi._version, wi.shape[0], wi.device)
+
+    def _ctx_for_sample(self, wi):
+        """Buffer the sample launch fills for ``wi`` (None when the cache is off or the wavefront is over the cap)."""
+        self._ctx = None
+        if not self.context_cache or not isinstance(wi, torch.Tensor) or wi.dim() != 2 or wi.shape[0] == 0:
+            return None
+        n = wi.shape[0]
+        need = self.sampler.context_floats(n)
+        if need * 4 > self.context_cache_max_bytes:
+            return None
+        buf = getattr(self, "_ctx_buf", None)
+        if buf is None or buf.numel() < need or buf.device != wi.device:
+            buf = self._ctx_buf = torch.empty((need,), dtype=torch.float32, device=wi.device)
+        # the key also pins the tensor object: a freed-and-reallocated wi with the same address cannot alias it
+        self._ctx = (self._wi_key(wi), wi, buf)
+        return buf
+
+    def _ctx_for_pdf(self, wi):
+        c = self._ctx
+        if c is None or not isinstance(wi, torch.Tensor) or self._wi_key(wi) != c[0]:
+            return None
+        return c[2]
+
+    def invalidate_context(self):
+        """Drop the cached context.  The cache trusts torch's version counter: code that rewrites the ``wi`` storage
+        through a raw pointer (a native kernel, DLPack) must either bump it
+        (``torch.autograd.graph.increment_version(wi)``), call this, or construct the plugin with
+        ``context_cache=False``."""
+        self._ctx = None
 
     def sample_pdf_t(self, wi: torch.Tensor, wl: torch.Tensor, x0: Optional[torch.Tensor] = None,
                      seed: Optional[int] = None, offset: int = 0):

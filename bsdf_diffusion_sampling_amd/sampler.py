@@ -83,6 +83,7 @@ class FlowSampler:
         if getattr(self, "_h", None):
             self._L.bsdfd_destroy(self._h)
             self._h = None
+            self._hi = 0  # the operator library rejects a null handle (TORCH_CHECK) instead of touching freed memory
 
     def __del__(self):
         try:
@@ -124,6 +125,28 @@ class FlowSampler:
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- per-query context (bsdfd_context_bytes / bsdfd_plugin_{sample,pdf}_ctx) ----
+    def context_floats(self, n: int, n_segments: int = 1) -> int:
+        """Size (in float32 elements) of the opaque per-query context of an n-query call."""
+        if not getattr(self, "_h", None):
+            raise RuntimeError("bsdfd: null handle")
+        b = int(self._L.bsdfd_context_bytes(self._h, n, n_segments))
+        if b < 0:
+            raise RuntimeError("bsdfd_context_bytes: bad arguments")
+        return b // 4
+
+    def new_context(self, n: int, n_segments: int = 1) -> torch.Tensor:
+        """Device buffer a ``plugin_sample(..., ctx_out=)`` call fills and ``plugin_pdf(..., ctx_in=)`` reads."""
+        return torch.empty((self.context_floats(n, n_segments),), dtype=torch.float32, device=self.device)
+
+    def _chk_ctx(self, ctx: torch.Tensor, n: int, n_segments: int = 1) -> torch.Tensor:
+        need = self.context_floats(n, n_segments)
+        if (not isinstance(ctx, torch.Tensor) or ctx.device != self.device or ctx.dtype != torch.float32 or ctx.dim() != 1
+                or not ctx.is_contiguous() or ctx.numel() < need or ctx.data_ptr() % 16):
+            raise RuntimeError(f"context must be a contiguous, 16-byte aligned float32 tensor of >= {need} elements on "
+                               f"{self.device} (FlowSampler.new_context)")
+        return ctx
 
     def flops_per_query(self, T: int) -> int:
         return int(self._L.bsdfd_flops_per_query(self._h, T))
@@ -184,7 +207,12 @@ class FlowSampler:
 
     # ---- plugin level (tensor core of MyBSDF.sample / MyBSDF.pdf) ----
     def plugin_sample(self, wi, x0=None, T: int = 4, variant: int = _lib.PLUGIN_MEASURED, seed: int = 0,
-                      offset: int = 0, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+                      offset: int = 0, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                      ctx_out: Optional[torch.Tensor] = None):
+        """``ctx_out`` (``new_context(N)``): also write the per-query context a following ``plugin_pdf(wi, .,
+        ctx_in=ctx_out)`` for the SAME ``wi`` reads instead of recomputing the prologue (identical results)."""
+        if ctx_out is not None:
+            return self._plugin_sample_ctx(wi, x0, T, variant, seed, offset, out, ctx_out)
         if self._ops is not None:
             self._dev_chk(wi, "wi")
             if out is None:
@@ -202,6 +230,29 @@ class FlowSampler:
         with torch.cuda.device(self.device):
             _lib.check(self._L.bsdfd_plugin_sample(self._h, variant, _ptr(wi), _ptr(x0), seed, offset, n, T,
                                                    _ptr(wo), _ptr(pdf), self._stream()))
+        return wo, pdf
+
+    def _plugin_sample_ctx(self, wi, x0, T, variant, seed, offset, out, ctx):
+        if self._ops is not None:
+            self._dev_chk(wi, "wi")
+            self._chk_ctx(ctx, wi.shape[0])
+            if out is None:
+                out = (torch.empty((wi.shape[0], 3), dtype=torch.float32, device=self.device),
+                       torch.empty((wi.shape[0],), dtype=torch.float32, device=self.device))
+            self._ops.plugin_sample_ctx_out(self._hi, variant, wi, x0, _i64(seed), _i64(offset), T, out[0], out[1], ctx)
+            return out[0], out[1]
+        wi = self._chk(wi, 3, "wi")
+        n = wi.shape[0]
+        x0 = self._chk(x0, 2, "x0", n)
+        self._chk_ctx(ctx, n)
+        if out is None:
+            wo = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+            pdf = torch.empty((n,), dtype=torch.float32, device=self.device)
+        else:
+            wo, pdf = self._chk(out[0], 3, "out wo", n), self._chk1(out[1], n, "out pdf")
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.bsdfd_plugin_sample_ctx(self._h, variant, _ptr(wi), _ptr(x0), seed, offset, n, T,
+                                                       _ptr(wo), _ptr(pdf), _ptr(ctx), self._stream()))
         return wo, pdf
 
     def plugin_sample_pdf(self, wi, wl, x0=None, T: int = 4, variant: int = _lib.PLUGIN_MEASURED, seed: int = 0,
@@ -228,7 +279,25 @@ class FlowSampler:
         return wo, pdf_o, pdf_l
 
     def plugin_pdf(self, wi, wo, T: int = 4, variant: int = _lib.PLUGIN_MEASURED,
-                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   out: Optional[torch.Tensor] = None, ctx_in: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``ctx_in``: the context ``plugin_sample(wi, ..., ctx_out=)`` wrote for this very ``wi`` array."""
+        if ctx_in is not None:
+            if self._ops is not None:
+                self._dev_chk(wi, "wi")
+                self._chk_ctx(ctx_in, wi.shape[0])
+                if out is None:
+                    out = torch.empty((wi.shape[0],), dtype=torch.float32, device=self.device)
+                self._ops.plugin_pdf_ctx_out(self._hi, variant, wi, wo, T, out, ctx_in)
+                return out
+            wi = self._chk(wi, 3, "wi")
+            n = wi.shape[0]
+            wo = self._chk(wo, 3, "wo", n)
+            self._chk_ctx(ctx_in, n)
+            pdf = torch.empty((n,), dtype=torch.float32, device=self.device) if out is None else self._chk1(out, n, "out pdf")
+            with torch.cuda.device(self.device):
+                _lib.check(self._L.bsdfd_plugin_pdf_ctx(self._h, variant, _ptr(wi), _ptr(wo), n, T, _ptr(pdf),
+                                                        _ptr(ctx_in), self._stream()))
+            return pdf
         if self._ops is not None:
             self._dev_chk(wi, "wi")
             if out is None:

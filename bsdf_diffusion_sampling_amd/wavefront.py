@@ -141,6 +141,8 @@ class WavefrontRenderer:
             _lib.check(_lib.lib().bsdfd_wf_primary(C.byref(self.scene), row_begin, row_end, spp, seed, pass_idx,
                                                    p(b["wi"]), p(b["wl"]), p(b["nrm"]), p(b["dir"]),
                                                    p(b["mat"]) if "mat" in b else None, self._stream()))
+        # written through raw pointers: tell torch (the plugin cores key their per-query context cache on wi._version)
+        torch.autograd.graph.increment_version([b["wi"], b["wl"], b["nrm"], b["dir"]])
         return b
 
     def shade(self, row_begin: int, row_end: int, spp: int, b, film: torch.Tensor):

@@ -117,6 +117,13 @@ def test_mixed_material_table_matches_per_material_calls():
     plan = tab.bucket(ids)
     c = tab.sample(plan, wi, seed=11, offset=5)
     assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]) and torch.equal(tab.pdf(plan, wi, a[0]), tab.pdf(ids, wi, a[0]))
+    # per-query contexts: sample(ctx=) fills them, pdf(ctx=) of the same plan and wi reads them — bit-identical
+    cx = {}
+    d = tab.sample(plan, wi, seed=11, offset=5, ctx=cx)
+    assert torch.equal(a[0], d[0]) and torch.equal(a[1], d[1]) and len(cx) == 1
+    assert torch.equal(tab.pdf(plan, wi, wl, ctx=cx), tab.pdf(plan, wi, wl))
+    with pytest.raises(ValueError, match="context"):
+        tab.pdf(plan, wi, wl, ctx={})
     # an id with no queries is fine; so is a single-row bucket
     ids2 = torch.zeros(1000, dtype=torch.int64, device=_dev())
     ids2[7] = 2
@@ -197,6 +204,15 @@ def test_mixed_domains_and_more_than_64_buckets():
     a = big.sample(ids, wi, seed=8)
     b = big.sample(ids, wi, seed=8, segmented=False)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.isfinite(a[1]).all()
+    # per-query contexts across interleaved runs and a launch split at 64 buckets (context slots are numbered by bucket)
+    for t in (tab, big):
+        idt = ids % len(t)
+        cx = {}
+        wo_c, pdf_c = t.sample(idt, wi, seed=8, ctx=cx)
+        wo_r, pdf_r = t.sample(idt, wi, seed=8)
+        assert torch.equal(wo_c, wo_r) and torch.equal(pdf_c, pdf_r) and len(cx) >= 2
+        wl = _wi("spherical", n, 21)
+        assert torch.equal(t.pdf(idt, wi, wl, ctx=cx), t.pdf(idt, wi, wl))
 
 
 def test_all_shipped_weight_sets_run_and_are_sane():

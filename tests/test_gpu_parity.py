@@ -495,3 +495,84 @@ def test_plugin_core_sample_pdf_t():
     wo2, po2 = plug.sample_t(wi, seed=7)
     assert torch.allclose(wo, wo2, atol=2e-6, rtol=0) and torch.allclose(po, po2, rtol=2e-5, atol=0)
     assert torch.allclose(pl, plug.pdf_t(wi, wl), rtol=2e-5, atol=0)
+
+
+@pytest.mark.parametrize("stem,variant", [("chm_orange_rgb_disk", 0), ("aniso_miro_7_rgb_disk", 0), ("aniso_miro_7_rgb_spherical", 0),
+                                          ("bsdf_3_spherical", 1), ("aniso_miro_7_rgb_spherical_complex", 0)])
+@pytest.mark.parametrize("n", [1, 17, 4097, 30001])
+def test_per_query_context_gives_bit_identical_results(stem, variant, n):
+    """bsdfd_plugin_sample_ctx writes what depends on wi alone (conditioning term of layer 1, base-net outputs);
+    bsdfd_plugin_pdf_ctx reads it instead of re-evaluating the prologue the reference evaluates once per Euler step
+    (rendering/utils/model.py:494) and twice per sample (mlp_brdf_sampling.py:20,24).  Results must not move by a bit,
+    for any T, ragged sizes, injected and in-kernel base draws."""
+    g, fw = load_case(stem)
+    s = _sampler(fw, "split3")
+    rng = np.random.default_rng(n)
+    def dirs(lo):
+        z, ph = rng.uniform(lo, 1.0, size=n), rng.uniform(0, 2 * np.pi, size=n)
+        r = np.sqrt(1 - z * z)
+        return _t(np.stack([r * np.cos(ph), r * np.sin(ph), z], 1))
+    wi, wl = dirs(0.05), dirs(-1.0 if variant else 0.02)
+    T = 4 if fw.domain == 0 else 8
+    ctx = s.new_context(n)
+    assert ctx.numel() * 4 == ((n + 15) // 16 + 1) * ((fw.width // 16) * 64 + 16) * 16
+    ctx.fill_(float("nan"))
+    for x0 in (None, _t(np.tile(g["x0"], (n // 2048 + 1, 1))[:n])):
+        wo, p = s.plugin_sample(wi, x0, T=T, variant=variant, seed=3, offset=11)
+        wo_c, p_c = s.plugin_sample(wi, x0, T=T, variant=variant, seed=3, offset=11, ctx_out=ctx)
+        assert torch.equal(wo, wo_c) and torch.equal(p, p_c)      # writing the context does not change sample()
+        for Tp in (T, 3):                                          # the context does not depend on T
+            ref = s.plugin_pdf(wi, wl, T=Tp, variant=variant)
+            assert torch.equal(ref, s.plugin_pdf(wi, wl, T=Tp, variant=variant, ctx_in=ctx))
+            out = torch.empty_like(ref)
+            assert s.plugin_pdf(wi, wl, T=Tp, variant=variant, ctx_in=ctx, out=out) is out and torch.equal(out, ref)
+    # a context is written by sample and read by pdf only; size and alignment are checked
+    import ctypes as C
+    from bsdf_diffusion_sampling_amd import _lib
+    L = _lib.lib()
+    p_ = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    with pytest.raises(RuntimeError, match="context"):
+        s.plugin_pdf(wi, wl, T=T, variant=variant, ctx_in=ctx[:-64])
+    with pytest.raises(RuntimeError, match="aligned"):
+        _lib.check(L.bsdfd_plugin_pdf_ctx(s._h, variant, p_(wi), p_(wl), n, T, p_(p), C.c_void_p(ctx.data_ptr() + 4), None))
+    assert L.bsdfd_context_bytes(s._h, -1, 1) == -1 and L.bsdfd_context_bytes(s._h, 16, 0) == -1
+    # NULL context = the plain calls
+    _lib.check(L.bsdfd_plugin_pdf_ctx(s._h, variant, p_(wi), p_(wl), n, T, p_(p), None, None))
+    assert torch.equal(p, s.plugin_pdf(wi, wl, T=T, variant=variant))
+
+
+def test_plugin_core_context_cache():
+    """MyBSDF.sample(si) followed by MyBSDF.pdf(si, wo) for the same si (rendering/brdf_measured_disk.py:59,112): the
+    core caches the per-query context keyed on the identity and version of si.wi."""
+    from bsdf_diffusion_sampling_amd.brdf_measured_spherical import MyBSDF
+    from bsdf_diffusion_sampling_amd.plugin_base import SurfaceInteraction
+    plug = MyBSDF({"filename": "chm_orange_rgb", "measured": False})
+    off = MyBSDF({"filename": "chm_orange_rgb", "measured": False, "context_cache": False})
+    rng = np.random.default_rng(3)
+    z, ph = rng.uniform(0.1, 1.0, size=5000), rng.uniform(0, 2 * np.pi, size=5000)
+    wi = _t(np.stack([np.sqrt(1 - z * z) * np.cos(ph), np.sqrt(1 - z * z) * np.sin(ph), z], 1))
+    wl = wi.flip(0).contiguous()
+    si = SurfaceInteraction(wi)
+    bs, _ = plug.sample(None, si, seed=5)
+    assert plug._ctx is not None and off._ctx_for_sample(wi) is None
+    assert plug._ctx_for_pdf(wi) is not None
+    p_hit = plug.pdf(None, si, wl)
+    assert torch.equal(p_hit, off.pdf(None, si, wl))
+    # another wi tensor, or the same tensor modified in place: no hit, still correct
+    wi2 = wi.clone()
+    assert plug._ctx_for_pdf(wi2) is None
+    wi.mul_(-1.0).mul_(-1.0)  # same values, version bumped
+    assert plug._ctx_for_pdf(wi) is None
+    assert torch.equal(plug.pdf(None, si, wl), p_hit)
+    # a raw-pointer writer bumps the version explicitly
+    plug.sample(None, si, seed=5)
+    assert plug._ctx_for_pdf(wi) is not None
+    torch.autograd.graph.increment_version(wi)
+    assert plug._ctx_for_pdf(wi) is None
+    plug.sample(None, si, seed=5)
+    plug.invalidate_context()
+    assert plug._ctx_for_pdf(wi) is None
+    # over the cap: no cache, same results
+    small = MyBSDF({"filename": "chm_orange_rgb", "measured": False, "context_cache_max_bytes": 1024})
+    small.sample(None, si, seed=5)
+    assert small._ctx is None and torch.equal(small.pdf(None, si, wl), p_hit)
