@@ -74,16 +74,30 @@ def test_full_size_properties(stem, domain, n, T):
         mu, kappa = orc.base_von_mises_params(cond)
         x0 = orc.base_sample(cond, rng.standard_normal(4096), phi=rng.vonmises(mu, kappa))
         wo_o, pdf_o = O.plugin_sample_spherical(orc, wi_np, x0, T=T)
-    x0_t = torch.from_numpy(x0.astype(np.float32)).to(_dev())
+    # both sides flow the SAME fp32 base draw (the oracle in fp64 arithmetic, and once more in fp32 arithmetic: the
+    # distance between those two is the reference-class fp32 noise of these very rows, incl. the plugin's fp32
+    # acos / atan2 / sincos chain — rendering/brdf_measured_spherical.py:35-39)
+    x0 = x0.astype(np.float32)
+    x0_t = torch.from_numpy(x0).to(_dev())
+    wi32 = wis.cpu().numpy()
+    orc32 = O.Oracle(fw, np.float32)
+    if domain == "disk":
+        wo_o, pdf_o = O.plugin_sample_disk(orc, wi_np, x0.astype(np.float64), T=T)
+        wo_32, pdf_32 = O.plugin_sample_disk(orc32, wi32, x0, T=T)
+    else:
+        wo_o, pdf_o = O.plugin_sample_spherical(orc, wi_np, x0.astype(np.float64), T=T)
+        wo_32, pdf_32 = O.plugin_sample_spherical(orc32, wi32, x0, T=T)
     wo_s, pdf_s = s.plugin_sample(wis, x0_t, T=T)
-    # the oracle flows the fp64 x0, the kernel its fp32 rounding: compare at 2e-4
-    assert np.abs(wo_s.cpu().numpy() - wo_o).max() < 2e-4
-    _, acc = orc.flow(x0, cond, T, reverse=False)
+    _, acc = orc.flow(x0.astype(np.float64), cond, T, reverse=False)
     sel = (np.abs(acc) > 1e-3) & (np.abs(acc) < 1e3) & (np.abs(pdf_o) > 1e-6 * np.percentile(np.abs(pdf_o), 99))
-    if domain != "disk":
-        sel &= np.sqrt(wo_o[:, 0] ** 2 + wo_o[:, 1] ** 2) > 1e-2
+    err_wo, noise_wo = np.abs(wo_s.cpu().numpy() - wo_o), np.abs(wo_32.astype(np.float64) - wo_o)
     rel = np.abs(pdf_s.cpu().numpy() - pdf_o)[sel] / np.abs(pdf_o[sel])
-    assert np.percentile(rel, 99) < 5e-4, np.percentile(rel, 99)
+    noise = np.abs(pdf_32.astype(np.float64) - pdf_o)[sel] / np.abs(pdf_o[sel])
+    from test_gpu_parity import _record
+    _record(f"full_size_subsample[{stem}:{n}]", wo_p99=np.percentile(err_wo, 99), wo_max=err_wo.max(), pdf_median=np.median(rel),
+            pdf_p99=np.percentile(rel, 99), fp32_oracle_wo_max=noise_wo.max(), fp32_oracle_pdf_p99=np.percentile(noise, 99))
+    assert np.percentile(err_wo, 99) <= 1e-5 and err_wo.max() <= max(1e-4, 2 * noise_wo.max())
+    assert np.percentile(rel, 99) <= max(1e-4, 2 * np.percentile(noise, 99)), (np.percentile(rel, 99), np.percentile(noise, 99))
 
 
 def test_mixed_material_table_matches_per_material_calls():

@@ -6,6 +6,8 @@ unmodified.  Bounds: the fp64 oracle must agree with the reference's own fp64 ru
 to round-off (1e-10), and with the reference's fp32 run to the fp32 noise floor
 measured in BASELINE.md §2 (median ~2e-6, p99 <= 2e-4 incl. near-singular rows).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -155,3 +157,49 @@ def test_disk_reflow_teacher_matches_reference(T):
     x, _ = O.Oracle(fw).flow(g["x0"], g["wi"], T, reverse=False)
     assert np.abs(x - g[f"x_T{T}_f64"]).max() < 1e-10
     assert np.abs(x - g[f"x_T{T}_f32"]).max() < 5e-5
+
+
+PLUGIN_CASES = ["aniso_miro_7_rgb_disk", "chm_orange_rgb_disk", "vch_silk_blue_rgb_disk", "aniso_miro_7_rgb_spherical",
+                "chm_orange_rgb_spherical", "bsdf_3_spherical"]
+
+
+@pytest.mark.parametrize("stem", PLUGIN_CASES)
+def test_plugin_level_oracle_vs_reference_plugin_goldens(stem):
+    """SURVEY.md §8(c) last row: plugin-level (wo3, pdf_sa) after guards.  tests/golden/<stem>_plugin.npz holds the
+    reference's own operators followed by the plugins' tensor ops (make_plugin_golden.py names the lines); the oracle's
+    plugin-level restatement must reproduce the reference's fp64 run to round-off and its fp32 run to fp32 noise."""
+    from conftest import GOLDEN, load_case
+    _, fw = load_case(stem)
+    p = np.load(os.path.join(GOLDEN, stem + "_plugin.npz"))
+    orc = O.Oracle(fw)
+    T, full = int(p["meta_T"]), bool(p["meta_full_sphere"])
+    if fw.domain == 0:
+        wo_o, pdf_o = O.plugin_sample_disk(orc, p["wi3"], p["x0"], T=T)
+        pl_o = O.plugin_pdf_disk(orc, p["pdf_wi3"], p["pdf_wo3"], T=T)
+        ps_o = O.plugin_pdf_disk(orc, p["wi3"], p["sample_wo3"], T=T)
+    else:
+        wo_o, pdf_o = O.plugin_sample_spherical(orc, p["wi3"].astype(np.float64), p["x0"], T=T, full_sphere=full)
+        pl_o = O.plugin_pdf_spherical(orc, p["pdf_wi3"].astype(np.float64), p["pdf_wo3"].astype(np.float64), T=T, full_sphere=full)
+        ps_o = O.plugin_pdf_spherical(orc, p["wi3"].astype(np.float64), p["sample_wo3"].astype(np.float64), T=T, full_sphere=full)
+    # fp64 run of the reference + the plugin ops in fp64: round-off agreement, zeros (guards) in the same rows
+    assert np.abs(wo_o - p["sample_wo3_f64"]).max() < 1e-12
+    ref = p["sample_pdf_sa_f64"]
+    assert np.array_equal(ref == 0, pdf_o == 0)
+    nz = ref != 0
+    assert (np.abs(pdf_o - ref)[nz] / np.abs(ref[nz])).max() < 1e-9
+    if fw.domain == 0:  # the guard was exercised: r^2 >= 0.995 rows give wo = (0, 0, 1), pdf = 0
+        bad = (p["sample_wo3"][:, 0] == 0) & (p["sample_wo3"][:, 1] == 0)
+        assert bad.sum() >= 1 and np.all(p["sample_pdf_sa"][bad] == 0) and np.all(pdf_o[bad] == 0)
+    # fp32 run (what the plugins really compute): fp32 noise only
+    scale = np.percentile(np.abs(ref), 99)
+    ok = np.abs(ref) > 1e-6 * scale
+    rel32 = np.abs(p["sample_pdf_sa"] - ref)[ok] / np.abs(ref[ok])
+    assert np.median(rel32) < 1e-5 and np.percentile(rel32, 99) < 3e-4
+    assert np.percentile(np.abs(p["sample_wo3"] - p["sample_wo3_f64"]), 99) < 1e-5
+    # pdf(): the reference forces fp32 (mlp_brdf_sampling.py:71,146) — compare at fp32 noise; masked lanes are exactly 0
+    for got, want in ((p["pdf_sa"], pl_o), (p["pdf_sa_of_samples"], ps_o)):
+        okp = np.abs(want) > 1e-6 * np.percentile(np.abs(want), 99)
+        r = np.abs(got - want)[okp] / np.abs(want[okp])
+        assert np.median(r) < 2e-5 and np.percentile(r, 99) < 3e-4
+    if not full:
+        assert np.all(p["pdf_sa"][:16] == 0) and np.all(pl_o[:16] == 0)   # cos(theta_o) <= 0 / cos(theta_i) <= 0 lanes
