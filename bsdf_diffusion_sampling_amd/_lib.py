@@ -29,8 +29,8 @@ EXPORTS = (
     "bsdfd_flops_per_query", "bsdfd_network_sampling", "bsdfd_network_pdf",
     "bsdfd_plugin_sample", "bsdfd_plugin_pdf", "bsdfd_plugin_sample_pdf", "bsdfd_plugin_sample_multi", "bsdfd_plugin_pdf_multi",
     "bsdfd_plugin_sample_pdf_multi",
-    "bsdfd_context_bytes", "bsdfd_plugin_sample_ctx", "bsdfd_plugin_pdf_ctx", "bsdfd_plugin_sample_multi_ctx",
-    "bsdfd_plugin_pdf_multi_ctx",
+    "bsdfd_context_bytes", "bsdfd_plugin_sample_ex", "bsdfd_plugin_pdf_ex", "bsdfd_plugin_sample_multi_ex",
+    "bsdfd_plugin_pdf_multi_ex", "bsdfd_plugin_sample_pdf_multi_ex",
     "bsdfd_flow_samples_only", "bsdfd_wf_primary", "bsdfd_wf_shade",
     "bsdfd_positional_encoding", "bsdfd_bucket_workspace_bytes", "bsdfd_bucket_by_material",
     "bsdfd_gather_lanes", "bsdfd_scatter_lanes",
@@ -50,6 +50,20 @@ class WfScene(C.Structure):
                 ("n_extra_spheres", C.c_int32), ("extra_spheres", (C.c_float * 4) * 31), ("has_plane", C.c_int32),
                 ("plane_y", C.c_float), ("checker_scale", C.c_float), ("checker_color0", C.c_float),
                 ("checker_color1", C.c_float)]
+
+
+class Opts(C.Structure):
+    """bsdfd_opts (include/bsdfd.h): optional arguments of the plugin-level *_ex calls."""
+    _fields_ = [("ctx_out", C.c_void_p), ("ctx_in", C.c_void_p), ("rng_index", C.c_void_p)]
+
+
+def opts(ctx_out=None, ctx_in=None, rng_index=None, byte_offset_rng: int = 0):
+    """A bsdfd_opts from torch tensors (None = absent); ``byte_offset_rng`` advances the rng_index pointer."""
+    o = Opts()
+    o.ctx_out = None if ctx_out is None else ctx_out.data_ptr()
+    o.ctx_in = None if ctx_in is None else ctx_in.data_ptr()
+    o.rng_index = None if rng_index is None else rng_index.data_ptr() + byte_offset_rng
+    return o
 
 
 class Desc(C.Structure):
@@ -115,10 +129,12 @@ def lib():
     L.bsdfd_plugin_pdf_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, i32, fp, vp]
     L.bsdfd_context_bytes.argtypes = [vp, i64, i32]
     L.bsdfd_context_bytes.restype = i64
-    L.bsdfd_plugin_sample_ctx.argtypes = [vp, i32, fp, fp, u64, u64, i64, i32, fp, fp, fp, vp]
-    L.bsdfd_plugin_pdf_ctx.argtypes = [vp, i32, fp, fp, i64, i32, fp, fp, vp]
-    L.bsdfd_plugin_sample_multi_ctx.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, u64, u64, i32, fp, fp, fp, vp]
-    L.bsdfd_plugin_pdf_multi_ctx.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, i32, fp, fp, vp]
+    op = C.POINTER(Opts)
+    L.bsdfd_plugin_sample_ex.argtypes = [vp, i32, fp, fp, u64, u64, i64, i32, fp, fp, op, vp]
+    L.bsdfd_plugin_pdf_ex.argtypes = [vp, i32, fp, fp, i64, i32, fp, op, vp]
+    L.bsdfd_plugin_sample_multi_ex.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, u64, u64, i32, fp, fp, op, vp]
+    L.bsdfd_plugin_pdf_multi_ex.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, i32, fp, op, vp]
+    L.bsdfd_plugin_sample_pdf_multi_ex.argtypes = [C.POINTER(vp), i32, C.POINTER(i64), i32, fp, fp, fp, u64, u64, i32, fp, fp, fp, op, vp]
     L.bsdfd_flow_samples_only.argtypes = [vp, fp, fp, i64, i32, fp, vp]
     L.bsdfd_wf_primary.argtypes = [C.POINTER(WfScene), i32, i32, i32, u64, u64, fp, fp, fp, fp, fp, vp]
     L.bsdfd_wf_shade.argtypes = [C.POINTER(WfScene), fp, i32, i32, i32, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, vp]

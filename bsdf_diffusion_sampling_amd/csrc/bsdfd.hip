@@ -90,6 +90,9 @@ struct KParams {
     // bsdfd_context_bytes: written by a sample launch (ctx_out), read instead of recomputed by a pdf launch (ctx_in)
     float* ctx_out;
     const float* ctx_in;
+    // sample: Philox counter of row i = offset + rng_index[i] (NULL: offset + i).  A bucketed wavefront passes the rows'
+    // ORIGINAL lane indices, so the draws do not depend on the bucketing, the sharding or the GPU count
+    const long long* rng_index;
     int seg_base;    // segmented launches: buckets served by EARLIER launches of the same call (context slot numbering)
     int chunk_log2;  // a wave takes 2^chunk_log2 consecutive-ish tiles per chunk (see the tile map in the kernel)
     int nseg;
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
         // ---------------- initial state ------------------------------------------------------------
         float x0 = (FUSED && !ph) ? xi0 : xs0, x1 = (FUSED && !ph) ? xi1 : xs1;
         if (op == OP_SAMPLE && p.in_b == nullptr) {  // draw x0 ~ D_base(. | omega_i) in-kernel
-            const unsigned long long ctr = p.offset + (unsigned long long)qi;
+            const unsigned long long ctr = p.offset + (unsigned long long)(p.rng_index ? p.rng_index[qi] : qi);
             const unsigned k0 = (unsigned)p.seed, k1 = (unsigned)(p.seed >> 32);
             unsigned u[4];
             philox4x32(k0, k1, (unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0x476175u, u);  // "Gau"
@@ -1103,10 +1106,18 @@ struct SegHost {
     long long q_begin, q_end;
 };
 
-struct CtxArg {  // per-query context buffers of a call (bsdfd_context_bytes) and the bucket numbering base
+struct CtxArg {  // optional arguments of a call (bsdfd_opts) and the bucket numbering base of segmented launches
     float* out = nullptr;
     const float* in = nullptr;
     int seg_base = 0;
+    const long long* rng_index = nullptr;
+    CtxArg() = default;
+    explicit CtxArg(const bsdfd_opts* o) {
+        if (!o) return;
+        out = static_cast<float*>(o->ctx_out);
+        in = static_cast<const float*>(o->ctx_in);
+        rng_index = reinterpret_cast<const long long*>(o->rng_index);
+    }
 };
 
 int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, uint64_t seed, uint64_t offset,
@@ -1127,6 +1138,8 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
         return fail(BSDFD_EINVAL, "the full-sphere plugin variant needs a spherical-domain handle");
     if ((ctx.out && op != OP_SAMPLE) || (ctx.in && op != OP_PDF))
         return fail(BSDFD_EINVAL, "a per-query context is written by sample calls and read by pdf calls only");
+    if (ctx.rng_index && (op == OP_PDF || op == OP_SAMPLES_ONLY))
+        return fail(BSDFD_EINVAL, "rng_index applies to calls that draw base samples (sample, sample_pdf)");
     if ((reinterpret_cast<uintptr_t>(ctx.out) | reinterpret_cast<uintptr_t>(ctx.in)) & 15u)
         return fail(BSDFD_EINVAL, "the per-query context buffer must be 16-byte aligned");
     int dev = -1;
@@ -1140,7 +1153,7 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     kp.N = N; kp.T = T; kp.n_hidden = h->n_hidden; kp.op = op; kp.io = io; kp.seed = seed; kp.offset = offset;
     kp.nseg = 0;
     kp.chunk_log2 = 3;
-    kp.ctx_out = ctx.out; kp.ctx_in = ctx.in; kp.seg_base = ctx.seg_base;
+    kp.ctx_out = ctx.out; kp.ctx_in = ctx.in; kp.seg_base = ctx.seg_base; kp.rng_index = ctx.rng_index;
 
     const int NM = h->width / 16;
     const int threads = threads_for(NM);
@@ -1427,47 +1440,45 @@ int64_t bsdfd_context_bytes(bsdfd_handle h, int64_t N, int32_t n_segments) {
     return ((N + 15) / 16 + n_segments) * per_tile;
 }
 
-int bsdfd_plugin_sample_ctx(bsdfd_handle h, int32_t variant, const float* wi, const float* x0, uint64_t seed,
-                            uint64_t offset, int64_t N, int32_t T, float* wo, float* pdf_sa, void* ctx_out, void* stream) {
+int bsdfd_plugin_sample_ex(bsdfd_handle h, int32_t variant, const float* wi, const float* x0, uint64_t seed,
+                           uint64_t offset, int64_t N, int32_t T, float* wo, float* pdf_sa, const bsdfd_opts* opts,
+                           void* stream) {
     if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
         return fail(BSDFD_EINVAL, "unknown plugin variant");
-    CtxArg c;
-    c.out = static_cast<float*>(ctx_out);
+    if (opts && opts->ctx_in) return fail(BSDFD_EINVAL, "sample calls write a per-query context (ctx_out), they do not read one");
     return run(h, OP_SAMPLE, variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, x0, seed, offset,
-               N, T, wo, pdf_sa, stream, nullptr, nullptr, nullptr, c);
+               N, T, wo, pdf_sa, stream, nullptr, nullptr, nullptr, CtxArg(opts));
 }
 
-int bsdfd_plugin_pdf_ctx(bsdfd_handle h, int32_t variant, const float* wi, const float* wo, int64_t N, int32_t T,
-                         float* pdf_sa, const void* ctx_in, void* stream) {
+int bsdfd_plugin_pdf_ex(bsdfd_handle h, int32_t variant, const float* wi, const float* wo, int64_t N, int32_t T,
+                        float* pdf_sa, const bsdfd_opts* opts, void* stream) {
     if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
         return fail(BSDFD_EINVAL, "unknown plugin variant");
-    CtxArg c;
-    c.in = static_cast<const float*>(ctx_in);
+    if (opts && opts->ctx_out) return fail(BSDFD_EINVAL, "pdf calls read a per-query context (ctx_in), they do not write one");
     return run(h, OP_PDF, variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, wo, 0, 0, N, T,
-               nullptr, pdf_sa, stream, nullptr, nullptr, nullptr, c);
+               nullptr, pdf_sa, stream, nullptr, nullptr, nullptr, CtxArg(opts));
 }
 
-int bsdfd_plugin_sample_multi_ctx(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end, int32_t variant,
-                                  const float* wi, const float* x0, uint64_t seed, uint64_t offset, int32_t T, float* wo,
-                                  float* pdf_sa, void* ctx_out, void* stream) {
+int bsdfd_plugin_sample_multi_ex(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end, int32_t variant,
+                                 const float* wi, const float* x0, uint64_t seed, uint64_t offset, int32_t T, float* wo,
+                                 float* pdf_sa, const bsdfd_opts* opts, void* stream) {
     if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
         return fail(BSDFD_EINVAL, "unknown plugin variant");
-    CtxArg c;
-    c.out = static_cast<float*>(ctx_out);
+    if (opts && opts->ctx_in) return fail(BSDFD_EINVAL, "sample calls write a per-query context (ctx_out), they do not read one");
     return run_multi(handles, n_handles, seg_end, OP_SAMPLE,
                      variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, x0, seed, offset, T, wo,
-                     pdf_sa, stream, nullptr, nullptr, c);
+                     pdf_sa, stream, nullptr, nullptr, CtxArg(opts));
 }
 
-int bsdfd_plugin_pdf_multi_ctx(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end, int32_t variant,
-                               const float* wi, const float* wo, int32_t T, float* pdf_sa, const void* ctx_in, void* stream) {
+int bsdfd_plugin_pdf_multi_ex(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end, int32_t variant,
+                              const float* wi, const float* wo, int32_t T, float* pdf_sa, const bsdfd_opts* opts,
+                              void* stream) {
     if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
         return fail(BSDFD_EINVAL, "unknown plugin variant");
-    CtxArg c;
-    c.in = static_cast<const float*>(ctx_in);
+    if (opts && opts->ctx_out) return fail(BSDFD_EINVAL, "pdf calls read a per-query context (ctx_in), they do not write one");
     return run_multi(handles, n_handles, seg_end, OP_PDF,
                      variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, wo, 0, 0, T, nullptr,
-                     pdf_sa, stream, nullptr, nullptr, c);
+                     pdf_sa, stream, nullptr, nullptr, CtxArg(opts));
 }
 
 int bsdfd_plugin_sample_pdf(bsdfd_handle h, int32_t variant, const float* wi, const float* x0, const float* wl,
@@ -1495,6 +1506,17 @@ int bsdfd_plugin_sample_pdf_multi(const bsdfd_handle* handles, int32_t n_handles
     return run_multi(handles, n_handles, seg_end, OP_SAMPLE_PDF,
                      variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, x0, seed, offset, T, wo,
                      pdf_wo, stream, wl, pdf_wl);
+}
+
+int bsdfd_plugin_sample_pdf_multi_ex(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end, int32_t variant,
+                                     const float* wi, const float* x0, const float* wl, uint64_t seed, uint64_t offset,
+                                     int32_t T, float* wo, float* pdf_wo, float* pdf_wl, const bsdfd_opts* opts, void* stream) {
+    if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE) return fail(BSDFD_EINVAL, "unknown plugin variant");
+    if (opts && (opts->ctx_in || opts->ctx_out))
+        return fail(BSDFD_EINVAL, "the fused sample+pdf call shares the prologue in registers; it takes no per-query context");
+    return run_multi(handles, n_handles, seg_end, OP_SAMPLE_PDF,
+                     variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, x0, seed, offset, T, wo,
+                     pdf_wo, stream, wl, pdf_wl, CtxArg(opts));
 }
 
 int bsdfd_plugin_pdf_multi(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end, int32_t variant,

@@ -229,8 +229,9 @@ int64_t context_floats(int64_t h, int64_t n, int64_t n_segments) {
     return b / 4;
 }
 
-void plugin_sample_ctx_out(int64_t h, int64_t variant, const Tensor& wi, const std::optional<Tensor>& x0, int64_t seed,
-                           int64_t offset, int64_t T, Tensor wo, Tensor pdf, Tensor ctx) {
+void plugin_sample_ex_out(int64_t h, int64_t variant, const Tensor& wi, const std::optional<Tensor>& x0, int64_t seed,
+                          int64_t offset, int64_t T, Tensor wo, Tensor pdf, const std::optional<Tensor>& ctx,
+                          const std::optional<Tensor>& rng_index) {
     const at::Device dev = wi.device();
     const float* wip = in2d(wi, 3, "wi", dev);
     const int64_t n = wi.size(0);
@@ -238,24 +239,32 @@ void plugin_sample_ctx_out(int64_t h, int64_t variant, const Tensor& wi, const s
     in2d(wo, 3, "wo (out)", dev, n);
     TORCH_CHECK(pdf.device() == dev && pdf.scalar_type() == at::kFloat && pdf.dim() == 1 && pdf.size(0) == n && pdf.is_contiguous(),
                 "pdf (out) must be a contiguous float32 tensor of shape [", n, "] on ", dev);
-    void* c = ctx_ptr(ctx, h, n, dev);
+    bsdfd_opts o{};
+    if (ctx.has_value()) o.ctx_out = ctx_ptr(*ctx, h, n, dev);
+    if (rng_index.has_value()) {
+        const Tensor& r = *rng_index;
+        TORCH_CHECK(r.device() == dev && r.scalar_type() == at::kLong && r.dim() == 1 && r.size(0) == n && r.is_contiguous(),
+                    "rng_index must be a contiguous int64 tensor of shape [", n, "] on ", dev);
+        o.rng_index = r.data_ptr<int64_t>();
+    }
     Launch L(dev);
-    ok(bsdfd_plugin_sample_ctx(as_handle(h), static_cast<int32_t>(variant), wip, x0p, static_cast<uint64_t>(seed),
-                               static_cast<uint64_t>(offset), n, static_cast<int32_t>(T), wo.data_ptr<float>(),
-                               pdf.data_ptr<float>(), c, L.stream));
+    ok(bsdfd_plugin_sample_ex(as_handle(h), static_cast<int32_t>(variant), wip, x0p, static_cast<uint64_t>(seed),
+                              static_cast<uint64_t>(offset), n, static_cast<int32_t>(T), wo.data_ptr<float>(),
+                              pdf.data_ptr<float>(), &o, L.stream));
 }
 
-void plugin_pdf_ctx_out(int64_t h, int64_t variant, const Tensor& wi, const Tensor& wo, int64_t T, Tensor pdf, const Tensor& ctx) {
+void plugin_pdf_ex_out(int64_t h, int64_t variant, const Tensor& wi, const Tensor& wo, int64_t T, Tensor pdf, const Tensor& ctx) {
     const at::Device dev = wi.device();
     const float* wip = in2d(wi, 3, "wi", dev);
     const int64_t n = wi.size(0);
     const float* wop = in2d(wo, 3, "wo", dev, n);
     TORCH_CHECK(pdf.device() == dev && pdf.scalar_type() == at::kFloat && pdf.dim() == 1 && pdf.size(0) == n && pdf.is_contiguous(),
                 "pdf (out) must be a contiguous float32 tensor of shape [", n, "] on ", dev);
-    const void* c = ctx_ptr(ctx, h, n, dev);
+    bsdfd_opts o{};
+    o.ctx_in = ctx_ptr(ctx, h, n, dev);
     Launch L(dev);
-    ok(bsdfd_plugin_pdf_ctx(as_handle(h), static_cast<int32_t>(variant), wip, wop, n, static_cast<int32_t>(T),
-                            pdf.data_ptr<float>(), c, L.stream));
+    ok(bsdfd_plugin_pdf_ex(as_handle(h), static_cast<int32_t>(variant), wip, wop, n, static_cast<int32_t>(T),
+                           pdf.data_ptr<float>(), &o, L.stream));
 }
 
 }  // namespace
@@ -277,7 +286,7 @@ TORCH_LIBRARY(bsdfd, m) {
           &plugin_sample_out);
     m.def("plugin_pdf_out(int handle, int variant, Tensor wi, Tensor wo, int T, Tensor(a!) pdf) -> ()", &plugin_pdf_out);
     m.def("context_floats(int handle, int n, int n_segments) -> int", &context_floats);
-    m.def("plugin_sample_ctx_out(int handle, int variant, Tensor wi, Tensor? x0, int seed, int offset, int T, Tensor(a!) wo, "
-          "Tensor(b!) pdf, Tensor(c!) ctx) -> ()", &plugin_sample_ctx_out);
-    m.def("plugin_pdf_ctx_out(int handle, int variant, Tensor wi, Tensor wo, int T, Tensor(a!) pdf, Tensor ctx) -> ()", &plugin_pdf_ctx_out);
+    m.def("plugin_sample_ex_out(int handle, int variant, Tensor wi, Tensor? x0, int seed, int offset, int T, Tensor(a!) wo, "
+          "Tensor(b!) pdf, Tensor(c!)? ctx, Tensor? rng_index) -> ()", &plugin_sample_ex_out);
+    m.def("plugin_pdf_ex_out(int handle, int variant, Tensor wi, Tensor wo, int T, Tensor(a!) pdf, Tensor ctx) -> ()", &plugin_pdf_ex_out);
 }

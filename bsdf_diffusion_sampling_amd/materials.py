@@ -72,7 +72,7 @@ class MaterialTable:
         return groups
 
     def _multi(self, which, members, seg_end_all, T, variant, wi_s, aux_s, seed, offset, out_wo, out_pdf, ctx=None,
-               gkey=None):
+               gkey=None, rng_rows=None):
         """``ctx`` (a dict, or None): per-query contexts (include/bsdfd.h, bsdfd_context_bytes) of the runs of this
         wavefront — a "sample" call creates and fills one buffer per (kernel signature, run), a "pdf" call on the same
         bucketed ``wi`` reads them instead of recomputing the per-query prologue.
@@ -108,17 +108,19 @@ class MaterialTable:
                     if cbuf is None:
                         raise ValueError("pdf(ctx=...) needs the context a sample(ctx=...) call of the SAME bucketed "
                                          "wavefront filled")
-            if which == "sample" and cbuf is not None:
+            if which == "sample" and (cbuf is not None or rng_rows is not None):
                 x0_p = None if aux_s is None else C.c_void_p(aux_s.data_ptr() + off_rows * 8)
-                r = L.bsdfd_plugin_sample_multi_ctx(arr_h, k, arr_e, variant, wi_p, x0_p, seed, offset + off_rows, T,
-                                                    C.c_void_p(out_wo.data_ptr() + off_rows * 12),
-                                                    C.c_void_p(out_pdf.data_ptr() + off_rows * 4),
-                                                    C.c_void_p(cbuf.data_ptr()), stream)
+                # rng_rows: counter of a row = offset + its ORIGINAL lane index (not its bucketed position)
+                o = _lib.opts(ctx_out=cbuf, rng_index=rng_rows, byte_offset_rng=off_rows * 8)
+                r = L.bsdfd_plugin_sample_multi_ex(arr_h, k, arr_e, variant, wi_p, x0_p, seed,
+                                                   offset if rng_rows is not None else offset + off_rows, T,
+                                                   C.c_void_p(out_wo.data_ptr() + off_rows * 12),
+                                                   C.c_void_p(out_pdf.data_ptr() + off_rows * 4), C.byref(o), stream)
             elif which == "pdf" and cbuf is not None:
-                r = L.bsdfd_plugin_pdf_multi_ctx(arr_h, k, arr_e, variant, wi_p,
-                                                 C.c_void_p(aux_s.data_ptr() + off_rows * 12), T,
-                                                 C.c_void_p(out_pdf.data_ptr() + off_rows * 4),
-                                                 C.c_void_p(cbuf.data_ptr()), stream)
+                o = _lib.opts(ctx_in=cbuf)
+                r = L.bsdfd_plugin_pdf_multi_ex(arr_h, k, arr_e, variant, wi_p,
+                                                C.c_void_p(aux_s.data_ptr() + off_rows * 12), T,
+                                                C.c_void_p(out_pdf.data_ptr() + off_rows * 4), C.byref(o), stream)
             elif which == "sample":
                 x0_p = None if aux_s is None else C.c_void_p(aux_s.data_ptr() + off_rows * 8)
                 r = L.bsdfd_plugin_sample_multi(arr_h, k, arr_e, variant, wi_p, x0_p, seed, offset + off_rows, T,
@@ -127,12 +129,13 @@ class MaterialTable:
             elif which == "sample_pdf":  # aux_s = (x0 or None, wl), out_pdf = (pdf_wo, pdf_wl)
                 x0_s, wl_s = aux_s
                 x0_p = None if x0_s is None else C.c_void_p(x0_s.data_ptr() + off_rows * 8)
-                r = L.bsdfd_plugin_sample_pdf_multi(arr_h, k, arr_e, variant, wi_p, x0_p,
-                                                    C.c_void_p(wl_s.data_ptr() + off_rows * 12), seed,
-                                                    offset + off_rows, T,
-                                                    C.c_void_p(out_wo.data_ptr() + off_rows * 12),
-                                                    C.c_void_p(out_pdf[0].data_ptr() + off_rows * 4),
-                                                    C.c_void_p(out_pdf[1].data_ptr() + off_rows * 4), stream)
+                o = _lib.opts(rng_index=rng_rows, byte_offset_rng=off_rows * 8)
+                r = L.bsdfd_plugin_sample_pdf_multi_ex(arr_h, k, arr_e, variant, wi_p, x0_p,
+                                                       C.c_void_p(wl_s.data_ptr() + off_rows * 12), seed,
+                                                       offset if rng_rows is not None else offset + off_rows, T,
+                                                       C.c_void_p(out_wo.data_ptr() + off_rows * 12),
+                                                       C.c_void_p(out_pdf[0].data_ptr() + off_rows * 4),
+                                                       C.c_void_p(out_pdf[1].data_ptr() + off_rows * 4), C.byref(o), stream)
             else:
                 r = L.bsdfd_plugin_pdf_multi(arr_h, k, arr_e, variant, wi_p,
                                              C.c_void_p(aux_s.data_ptr() + off_rows * 12), T,
@@ -243,12 +246,15 @@ class MaterialTable:
 
     def sample(self, material_id: torch.Tensor, wi: torch.Tensor, seed: int = 0, offset: int = 0,
                T: Optional[int] = None, x0: Optional[torch.Tensor] = None, segmented: bool = True,
-               bucketed: bool = False, ctx: Optional[dict] = None):
+               bucketed: bool = False, ctx: Optional[dict] = None, rng: str = "lane"):
         """wi [N,3], material_id [N] -> (wo [N,3], pdf_sa [N]) in the callers' order.
+        ``rng``: ``"lane"`` (default) — the Philox counter of a query is ``offset + its ORIGINAL lane index``, so the base
+        draws depend on neither the bucketing nor how the wavefront is sharded over calls / GPUs (a shard passes its
+        first lane's global index as ``offset``); ``"bucketed"`` — ``offset + row in the bucketed
+        array`` (what a caller that keeps no lane order would use).
         ``ctx``: a dict this call fills with the wavefront's per-query contexts; hand the same dict (and the same
         plan and ``wi``) to ``pdf(..., ctx=)`` and it skips the per-query prologue (identical results).
-        The Philox counter of a query is ``offset + its row in the bucketed (sorted-by-material)
-        array``, identical for the segmented and the per-bucket path.  ``bucketed=True``: ``material_id`` is a
+        Identical for the segmented and the per-bucket path.  ``bucketed=True``: ``material_id`` is a
         plan, ``wi`` / ``x0`` are already in bucket order (``gather(plan, wi)``) and the results stay in it."""
         wi = self._chk_in(wi, 3, "wi")
         x0 = self._chk_in(x0, 2, "x0", wi.shape[0])
@@ -263,21 +269,26 @@ class MaterialTable:
             x0_s = None if x0 is None else x0[rows].contiguous()
         wo_s = torch.empty_like(wi_s)
         pdf_s = torch.empty(wi_s.shape[0], dtype=torch.float32, device=wi.device)
+        if rng not in ("lane", "bucketed"):
+            raise ValueError("rng must be 'lane' or 'bucketed'")
+        rng_rows = rows.contiguous() if rng == "lane" else None
         if segmented:
             with torch.cuda.device(wi.device):
                 for (dom, w, nh, prec, Tm, var), members in self._groups().items():
                     self._multi("sample", members, seg_end, Tm if T is None else T, var, wi_s, x0_s, seed, offset,
-                                wo_s, pdf_s, ctx=ctx, gkey=(dom, w, nh, prec, var))
+                                wo_s, pdf_s, ctx=ctx, gkey=(dom, w, nh, prec, var), rng_rows=rng_rows)
         else:
             lo = 0
             for m, n in enumerate(counts):
                 if n == 0:
                     continue
                 sl = slice(lo, lo + n)
-                # same Philox keying as the segmented path: counter = offset + row in the bucketed array
+                # same Philox keying as the segmented path
                 self.samplers[m].plugin_sample(wi_s[sl], None if x0_s is None else x0_s[sl],
                                                T=self.T[m] if T is None else T, variant=self.variant[m],
-                                               seed=seed, offset=offset + lo, out=(wo_s[sl], pdf_s[sl]))
+                                               seed=seed, offset=offset if rng_rows is not None else offset + lo,
+                                               out=(wo_s[sl], pdf_s[sl]),
+                                               rng_index=None if rng_rows is None else rng_rows[sl])
                 lo += n
         if bucketed:
             return wo_s, pdf_s
@@ -289,7 +300,8 @@ class MaterialTable:
         return wo, pdf
 
     def sample_pdf(self, material_id, wi: torch.Tensor, wl: torch.Tensor, seed: int = 0, offset: int = 0,
-                   T: Optional[int] = None, x0: Optional[torch.Tensor] = None, return_bucketed: bool = False):
+                   T: Optional[int] = None, x0: Optional[torch.Tensor] = None, return_bucketed: bool = False,
+                   rng: str = "lane"):
         """sample(wi) and pdf(wi, wl) for the same material-tagged intersections, one launch per kernel
         signature (``bsdfd_plugin_sample_pdf_multi``) -> (wo [N,3], pdf(wo) [N], pdf(wl) [N]) in the callers' order."""
         wi = self._chk_in(wi, 3, "wi")
@@ -305,7 +317,7 @@ class MaterialTable:
         with torch.cuda.device(wi.device):
             for (dom, w, nh, prec, Tm, var), members in self._groups().items():
                 self._multi("sample_pdf", members, seg_end, Tm if T is None else T, var, wi_s, (x0_s, wl_s), seed,
-                            offset, wo_s, (po_s, pl_s))
+                            offset, wo_s, (po_s, pl_s), rng_rows=rows.contiguous() if rng == "lane" else None)
         full = n_mat == wi.shape[0]
         mk = torch.empty if full else torch.zeros
         wo = mk(wi.shape, dtype=torch.float32, device=wi.device)

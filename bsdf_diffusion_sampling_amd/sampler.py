@@ -208,11 +208,13 @@ class FlowSampler:
     # ---- plugin level (tensor core of MyBSDF.sample / MyBSDF.pdf) ----
     def plugin_sample(self, wi, x0=None, T: int = 4, variant: int = _lib.PLUGIN_MEASURED, seed: int = 0,
                       offset: int = 0, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                      ctx_out: Optional[torch.Tensor] = None):
+                      ctx_out: Optional[torch.Tensor] = None, rng_index: Optional[torch.Tensor] = None):
         """``ctx_out`` (``new_context(N)``): also write the per-query context a following ``plugin_pdf(wi, .,
-        ctx_in=ctx_out)`` for the SAME ``wi`` reads instead of recomputing the prologue (identical results)."""
-        if ctx_out is not None:
-            return self._plugin_sample_ctx(wi, x0, T, variant, seed, offset, out, ctx_out)
+        ctx_in=ctx_out)`` for the SAME ``wi`` reads instead of recomputing the prologue (identical results).
+        ``rng_index`` (int64 [N]): the Philox counter of row i is ``offset + rng_index[i]`` instead of ``offset + i``
+        (a bucketed wavefront passes the rows' original lane indices: draws independent of the bucketing)."""
+        if ctx_out is not None or rng_index is not None:
+            return self._plugin_sample_ex(wi, x0, T, variant, seed, offset, out, ctx_out, rng_index)
         if self._ops is not None:
             self._dev_chk(wi, "wi")
             if out is None:
@@ -232,27 +234,40 @@ class FlowSampler:
                                                    _ptr(wo), _ptr(pdf), self._stream()))
         return wo, pdf
 
-    def _plugin_sample_ctx(self, wi, x0, T, variant, seed, offset, out, ctx):
+    def _chk_index(self, idx, n):
+        if idx is None:
+            return None
+        if (not isinstance(idx, torch.Tensor) or idx.device != self.device or idx.dtype != torch.int64 or idx.dim() != 1
+                or idx.shape[0] != n or not idx.is_contiguous()):
+            raise RuntimeError(f"rng_index must be a contiguous int64 tensor of shape [{n}] on {self.device}")
+        return idx
+
+    def _plugin_sample_ex(self, wi, x0, T, variant, seed, offset, out, ctx, rng_index):
         if self._ops is not None:
             self._dev_chk(wi, "wi")
-            self._chk_ctx(ctx, wi.shape[0])
+            if ctx is not None:
+                self._chk_ctx(ctx, wi.shape[0])
+            self._chk_index(rng_index, wi.shape[0])
             if out is None:
                 out = (torch.empty((wi.shape[0], 3), dtype=torch.float32, device=self.device),
                        torch.empty((wi.shape[0],), dtype=torch.float32, device=self.device))
-            self._ops.plugin_sample_ctx_out(self._hi, variant, wi, x0, _i64(seed), _i64(offset), T, out[0], out[1], ctx)
+            self._ops.plugin_sample_ex_out(self._hi, variant, wi, x0, _i64(seed), _i64(offset), T, out[0], out[1], ctx, rng_index)
             return out[0], out[1]
         wi = self._chk(wi, 3, "wi")
         n = wi.shape[0]
         x0 = self._chk(x0, 2, "x0", n)
-        self._chk_ctx(ctx, n)
+        if ctx is not None:
+            self._chk_ctx(ctx, n)
+        self._chk_index(rng_index, n)
         if out is None:
             wo = torch.empty((n, 3), dtype=torch.float32, device=self.device)
             pdf = torch.empty((n,), dtype=torch.float32, device=self.device)
         else:
             wo, pdf = self._chk(out[0], 3, "out wo", n), self._chk1(out[1], n, "out pdf")
+        o = _lib.opts(ctx_out=ctx, rng_index=rng_index)
         with torch.cuda.device(self.device):
-            _lib.check(self._L.bsdfd_plugin_sample_ctx(self._h, variant, _ptr(wi), _ptr(x0), seed, offset, n, T,
-                                                       _ptr(wo), _ptr(pdf), _ptr(ctx), self._stream()))
+            _lib.check(self._L.bsdfd_plugin_sample_ex(self._h, variant, _ptr(wi), _ptr(x0), seed, offset, n, T,
+                                                      _ptr(wo), _ptr(pdf), C.byref(o), self._stream()))
         return wo, pdf
 
     def plugin_sample_pdf(self, wi, wl, x0=None, T: int = 4, variant: int = _lib.PLUGIN_MEASURED, seed: int = 0,
@@ -287,16 +302,17 @@ class FlowSampler:
                 self._chk_ctx(ctx_in, wi.shape[0])
                 if out is None:
                     out = torch.empty((wi.shape[0],), dtype=torch.float32, device=self.device)
-                self._ops.plugin_pdf_ctx_out(self._hi, variant, wi, wo, T, out, ctx_in)
+                self._ops.plugin_pdf_ex_out(self._hi, variant, wi, wo, T, out, ctx_in)
                 return out
             wi = self._chk(wi, 3, "wi")
             n = wi.shape[0]
             wo = self._chk(wo, 3, "wo", n)
             self._chk_ctx(ctx_in, n)
             pdf = torch.empty((n,), dtype=torch.float32, device=self.device) if out is None else self._chk1(out, n, "out pdf")
+            o = _lib.opts(ctx_in=ctx_in)
             with torch.cuda.device(self.device):
-                _lib.check(self._L.bsdfd_plugin_pdf_ctx(self._h, variant, _ptr(wi), _ptr(wo), n, T, _ptr(pdf),
-                                                        _ptr(ctx_in), self._stream()))
+                _lib.check(self._L.bsdfd_plugin_pdf_ex(self._h, variant, _ptr(wi), _ptr(wo), n, T, _ptr(pdf),
+                                                       C.byref(o), self._stream()))
             return pdf
         if self._ops is not None:
             self._dev_chk(wi, "wi")

@@ -18,7 +18,7 @@ EXT_PATH = os.path.join(_HERE, "libbsdfd_torch.so")
 SRC_PATH = os.path.join(_HERE, "csrc", "torch_ops.cpp")
 OPS = ("create_from_file", "create", "destroy", "flops_per_query", "network_sampling", "network_pdf", "flow_samples_only",
        "plugin_sample", "plugin_pdf", "plugin_sample_pdf", "plugin_sample_out", "plugin_pdf_out", "context_floats",
-       "plugin_sample_ctx_out", "plugin_pdf_ctx_out")
+       "plugin_sample_ex_out", "plugin_pdf_ex_out")
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -134,18 +134,28 @@ int bsdfd_plugin_sample_pdf(bsdfd_handle h, int32_t variant, const float* wi, co
  * recomputes it) and the base-density net's four outputs (evaluated twice per sample() by
  * rendering/utils/mlp_brdf_sampling.py:20,24) — 144 B per query for the 32-wide nets, 272 B for 64-wide.
  * A renderer calls sample(si) and then pdf(si, wl) for the SAME intersections (rendering/brdf_measured_disk.py:59,112
- * are both driven by one `si`): bsdfd_plugin_sample_ctx writes the context while it samples, bsdfd_plugin_pdf_ctx
- * reads it instead of re-evaluating the prologue (cart_to_spher(wi), 22 sin/cos, 20 fp32 MFMAs per 16 queries).
+ * are both driven by one `si`): bsdfd_plugin_sample_ex writes the context while it samples (opts->ctx_out),
+ * bsdfd_plugin_pdf_ex reads it (opts->ctx_in) instead of re-evaluating the prologue (cart_to_spher(wi), 22 sin/cos, 20 fp32 MFMAs per 16 queries).
  * Results are BIT-IDENTICAL to the calls without a context.  The buffer is opaque device memory of
  * bsdfd_context_bytes(h, N, n_segments) bytes (n_segments = 1 for single-material calls, = n_handles for *_multi
  * calls), 16-byte aligned, valid only for the handle(s), the wi array and — for *_multi — the seg_end layout it
  * was written with; T may differ between the two calls.  NULL context = the plain call. */
 int64_t bsdfd_context_bytes(bsdfd_handle h, int64_t N, int32_t n_segments);
-int bsdfd_plugin_sample_ctx(bsdfd_handle h, int32_t variant, const float* wi, const float* x0, uint64_t seed,
-                            uint64_t offset, int64_t N, int32_t T, float* wo, float* pdf_sa, void* ctx_out,
-                            void* hip_stream);
-int bsdfd_plugin_pdf_ctx(bsdfd_handle h, int32_t variant, const float* wi, const float* wo, int64_t N, int32_t T,
-                         float* pdf_sa, const void* ctx_in, void* hip_stream);
+
+/* Optional arguments of the plugin-level calls (NULL pointer / all-zero struct = the plain call). */
+typedef struct bsdfd_opts {
+    void* ctx_out;             /* sample calls: write the per-query context here                                   */
+    const void* ctx_in;        /* pdf calls: read the context a sample call wrote for the same wi array             */
+    const int64_t* rng_index;  /* sample calls: device array [N]; the Philox counter of row i is offset +
+                                * rng_index[i] instead of offset + i.  A wavefront that was bucketed by material
+                                * passes the rows' ORIGINAL lane indices here: the base draws then depend on neither
+                                * the bucketing nor the sharding / GPU count.                */
+} bsdfd_opts;
+int bsdfd_plugin_sample_ex(bsdfd_handle h, int32_t variant, const float* wi, const float* x0, uint64_t seed,
+                           uint64_t offset, int64_t N, int32_t T, float* wo, float* pdf_sa, const bsdfd_opts* opts,
+                           void* hip_stream);
+int bsdfd_plugin_pdf_ex(bsdfd_handle h, int32_t variant, const float* wi, const float* wo, int64_t N, int32_t T,
+                        float* pdf_sa, const bsdfd_opts* opts, void* hip_stream);
 
 /* Mixed-material batches (BASELINE.json configs[3]; the reference binds one plugin instance per material,
  * rendering/matpreview/disney_bsdf_array0_envmap.xml, and Mitsuba calls each instance on its lanes).
@@ -166,13 +176,18 @@ int bsdfd_plugin_sample_pdf_multi(const bsdfd_handle* handles, int32_t n_handles
                                   uint64_t seed, uint64_t offset, int32_t T, float* wo, float* pdf_wo,
                                   float* pdf_wl, void* hip_stream);
 
-/* the *_multi calls with a per-query context (see bsdfd_context_bytes; n_segments = n_handles) */
-int bsdfd_plugin_sample_multi_ctx(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end,
-                                  int32_t variant, const float* wi, const float* x0, uint64_t seed, uint64_t offset,
-                                  int32_t T, float* wo, float* pdf_sa, void* ctx_out, void* hip_stream);
-int bsdfd_plugin_pdf_multi_ctx(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end,
-                               int32_t variant, const float* wi, const float* wo, int32_t T, float* pdf_sa,
-                               const void* ctx_in, void* hip_stream);
+/* the *_multi calls with optional arguments (bsdfd_opts; a context spans n_segments = n_handles buckets) */
+int bsdfd_plugin_sample_multi_ex(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end,
+                                 int32_t variant, const float* wi, const float* x0, uint64_t seed, uint64_t offset,
+                                 int32_t T, float* wo, float* pdf_sa, const bsdfd_opts* opts, void* hip_stream);
+int bsdfd_plugin_pdf_multi_ex(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end,
+                              int32_t variant, const float* wi, const float* wo, int32_t T, float* pdf_sa,
+                              const bsdfd_opts* opts, void* hip_stream);
+/* bsdfd_plugin_sample_pdf_multi with opts->rng_index (the fused call takes no context: its prologue stays in registers) */
+int bsdfd_plugin_sample_pdf_multi_ex(const bsdfd_handle* handles, int32_t n_handles, const int64_t* seg_end,
+                                     int32_t variant, const float* wi, const float* x0, const float* wl, uint64_t seed,
+                                     uint64_t offset, int32_t T, float* wo, float* pdf_wo, float* pdf_wl,
+                                     const bsdfd_opts* opts, void* hip_stream);
 
 /* Reflow teacher sampling without the Jacobian: x <- x + v(x, t/T | omega_i)/T for T steps
  * (learning_repo_cleanup/spherical_domain_sampling.py:147-166, disk_domain_sampling.py:93-110 —

@@ -117,7 +117,7 @@ def test_mixed_material_table_matches_per_material_calls():
         wo_m, pdf_m = tab.samplers[m].plugin_sample(wi[sel].contiguous(), x0[sel].contiguous(), T=4)
         assert torch.equal(wo[sel], wo_m) and torch.equal(pdf[sel], pdf_m)
         assert torch.equal(p[sel], tab.samplers[m].plugin_pdf(wi[sel].contiguous(), wo[sel].contiguous(), T=4))
-    # segmented == one launch per bucket, bit for bit, also with the in-kernel RNG (counter = bucketed row)
+    # segmented == one launch per bucket, bit for bit, also with the in-kernel RNG (counter = offset + lane index)
     a = tab.sample(ids, wi, seed=11, offset=5)
     b = tab.sample(ids, wi, seed=11, offset=5, segmented=False)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
@@ -160,14 +160,21 @@ def test_plan_with_extra_bins_serves_sample_and_pdf():
     mat = ids < len(stems)
     assert 0 < int(mat.sum()) < n
     for seg in (True, False):
-        wo, pdf = tab.sample(plan, wi, seed=4, offset=7, segmented=seg)
+        wo, pdf = tab.sample(plan, wi, seed=4, offset=7, segmented=seg, rng="bucketed")
         assert torch.count_nonzero(wo[~mat]) == 0 and torch.count_nonzero(pdf[~mat]) == 0
         assert torch.isfinite(wo).all() and torch.isfinite(pdf).all()
         assert torch.allclose((wo[mat] ** 2).sum(1), torch.ones(int(mat.sum()), device=_dev()), atol=1e-4)
-        # the material lanes keep their relative (bucketed) order when the other lanes are dropped, so a table call on
-        # them alone sees the same Philox counters
-        wo_m, pdf_m = tab.sample(ids[mat], wi[mat].contiguous(), seed=4, offset=7, segmented=seg)
+        # rng="bucketed": the material lanes keep their relative (bucketed) order when the other lanes are dropped, so a
+        # table call on them alone sees the same Philox counters
+        wo_m, pdf_m = tab.sample(ids[mat], wi[mat].contiguous(), seed=4, offset=7, segmented=seg, rng="bucketed")
         assert torch.equal(wo[mat], wo_m) and torch.equal(pdf[mat], pdf_m)
+        # rng="lane" (the default): the counter of a lane is offset + its index in the callers' array, whatever the
+        # other lanes carry — relabelling the non-material lanes as one more material does not move the material lanes
+        wo_l, pdf_l = tab.sample(plan, wi, seed=4, offset=7, segmented=seg)
+        ids_all = torch.where(mat, ids, torch.zeros_like(ids))
+        wo_a, pdf_a = tab.sample(ids_all, wi, seed=4, offset=7, segmented=seg)
+        assert torch.equal(wo_l[mat], wo_a[mat]) and torch.equal(pdf_l[mat], pdf_a[mat])
+        assert not torch.equal(wo_l[mat], wo[mat])
         p = tab.pdf(plan, wi, wo, segmented=seg)
         assert torch.count_nonzero(p[~mat]) == 0
         assert torch.equal(p[mat], tab.pdf(ids[mat], wi[mat].contiguous(), wo[mat].contiguous(), segmented=seg))

@@ -527,8 +527,8 @@ def test_plugin_core_sample_pdf_t():
                                           ("bsdf_3_spherical", 1), ("aniso_miro_7_rgb_spherical_complex", 0)])
 @pytest.mark.parametrize("n", [1, 17, 4097, 30001])
 def test_per_query_context_gives_bit_identical_results(stem, variant, n):
-    """bsdfd_plugin_sample_ctx writes what depends on wi alone (conditioning term of layer 1, base-net outputs);
-    bsdfd_plugin_pdf_ctx reads it instead of re-evaluating the prologue the reference evaluates once per Euler step
+    """bsdfd_plugin_sample_ex(opts.ctx_out) writes what depends on wi alone (conditioning term of layer 1, base-net outputs);
+    bsdfd_plugin_pdf_ex(opts.ctx_in) reads it instead of re-evaluating the prologue the reference evaluates once per Euler step
     (rendering/utils/model.py:494) and twice per sample (mlp_brdf_sampling.py:20,24).  Results must not move by a bit,
     for any T, ragged sizes, injected and in-kernel base draws."""
     g, fw = load_case(stem)
@@ -560,11 +560,24 @@ def test_per_query_context_gives_bit_identical_results(stem, variant, n):
     with pytest.raises(RuntimeError, match="context"):
         s.plugin_pdf(wi, wl, T=T, variant=variant, ctx_in=ctx[:-64])
     with pytest.raises(RuntimeError, match="aligned"):
-        _lib.check(L.bsdfd_plugin_pdf_ctx(s._h, variant, p_(wi), p_(wl), n, T, p_(p), C.c_void_p(ctx.data_ptr() + 4), None))
+        o = _lib.Opts()
+        o.ctx_in = ctx.data_ptr() + 4
+        _lib.check(L.bsdfd_plugin_pdf_ex(s._h, variant, p_(wi), p_(wl), n, T, p_(p), C.byref(o), None))
+    with pytest.raises(RuntimeError, match="ctx_in|write"):   # a pdf call cannot be asked to write a context, and vice versa
+        _lib.check(L.bsdfd_plugin_pdf_ex(s._h, variant, p_(wi), p_(wl), n, T, p_(p), C.byref(_lib.opts(ctx_out=ctx)), None))
+    with pytest.raises(RuntimeError, match="ctx_out|read"):
+        _lib.check(L.bsdfd_plugin_sample_ex(s._h, variant, p_(wi), None, 0, 0, n, T, p_(wo), p_(p), C.byref(_lib.opts(ctx_in=ctx)), None))
     assert L.bsdfd_context_bytes(s._h, -1, 1) == -1 and L.bsdfd_context_bytes(s._h, 16, 0) == -1
     # NULL context = the plain calls
-    _lib.check(L.bsdfd_plugin_pdf_ctx(s._h, variant, p_(wi), p_(wl), n, T, p_(p), None, None))
+    _lib.check(L.bsdfd_plugin_pdf_ex(s._h, variant, p_(wi), p_(wl), n, T, p_(p), None, None))
     assert torch.equal(p, s.plugin_pdf(wi, wl, T=T, variant=variant))
+    # rng_index: the Philox counter of row i is offset + rng_index[i] — a permuted batch draws what the original draws
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(n)).to(_dev())
+    wo_a, p_a = s.plugin_sample(wi, None, T=T, variant=variant, seed=3, offset=11)
+    wo_b, p_b = s.plugin_sample(wi[perm].contiguous(), None, T=T, variant=variant, seed=3, offset=11, rng_index=perm)
+    assert torch.equal(wo_a[perm], wo_b) and torch.equal(p_a[perm], p_b)
+    with pytest.raises(RuntimeError, match="rng_index"):
+        s.plugin_sample(wi, None, T=T, variant=variant, rng_index=perm.int())
 
 
 def test_plugin_core_context_cache():
