@@ -76,3 +76,35 @@ def test_bench_self_launches_two_ranks(workload):
     ng = mg["Msamples_per_s_no_gather"]
     assert 0.3 * one["value"] < ng < 1.3 * one["value"], (one["value"], ng)
     assert two["value"] <= 1.05 * ng
+
+
+@pytest.mark.parametrize("workload", ["disk_1Mi_T8", "mixed_16Mi"])
+def test_bench_self_launches_eight_ranks_gloo(workload):
+    """The driver's launch shape at N = 8 (`python bench.py --gpus 8`), on the one GPU of this box through the gloo test
+    hook: rendezvous of 8 ranks, the all-reduce of the step size R, barrier + max-over-ranks timing, the three gather
+    modes, an 8-entry rank report — everything of the N = 8 control flow except the RCCL transport itself."""
+    args = ["--gpus", "8", "--workload", workload, "--steps", "2", "--warmup", "1", "--passes-per-step", "1", "--settle-ms", "20",
+            "--no-cpu-baseline", "--no-secondary"]
+    d = _run(args, {"BSDFD_BENCH_BACKEND": "gloo"}, timeout=1500)
+    _check_contract(d, 8, workload)
+    ranks = d["config"]["ranks"]
+    assert [r["rank"] for r in ranks] == list(range(8)) and [r["local_rank"] for r in ranks] == list(range(8))
+    assert d["config"]["distinct_devices"] == 1 and d["config"]["rccl_ranks"] == 0 and d["config"]["backend"] == "gloo"
+    mg = d["multi_gpu"]
+    assert mg["judged"] == "final" and mg["Msamples_per_s_no_gather"] > 0 and mg["Msamples_per_s_gather_every_step_overlapped"] > 0
+    assert mg["gather_bytes_per_rank"] == d["config"]["queries_per_wavefront_per_gpu"] * 16
+    assert d["config"]["queries_per_step"] == 8 * d["config"]["queries_per_wavefront_per_gpu"]
+
+
+def test_bench_refuses_to_oversubscribe_gpus_under_rccl():
+    """`--gpus 8` on a box with fewer GPUs and the real (RCCL) backend: every rank exits with a one-line reason before any
+    process group exists — no silent sharing of a device, no hang, no JSON line."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("needs a box with fewer than 8 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "BSDFD_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "refusing to oversubscribe" in (r.stdout + r.stderr)

@@ -15,14 +15,21 @@ import json
 import re
 import sys
 
-# measured issue cost, shader cycles per wave64 instruction per SIMD (tools/ubench/RESULTS.md)
-COST = {"v_mfma_f32_16x16x32_f16": 16.2, "v_mfma_f32_16x16x4_f32": 32.0, "v_mfma_f32_32x32x16_f16": 32.1,
-        "v_exp_f32": 7.0, "v_rcp_f32": 7.2, "v_log_f32": 7.0, "v_sqrt_f32": 7.0, "v_sin_f32": 7.0, "v_cos_f32": 7.0,
-        "v_rsq_f32": 7.0, "v_exp_f16": 7.0, "v_rcp_f16": 7.2,
-        "v_cvt_pk_f16_f32": 3.7, "v_cvt_pkrtz_f16_f32": 4.4, "v_perm_b32": 4.3, "v_cvt_f32_f16": 3.6,
-        "v_fma_mix_f32": 7.3, "v_fma_mixlo_f16": 7.3, "v_fma_mixhi_f16": 7.3}
-PK = 3.7      # v_pk_{fma,mul,add}_f32
-PLAIN = 2.4   # any other VALU
+# Occupancy of a SIMD's VALU issue path, shader cycles per wave64 instruction (tools/ubench/RESULTS.md, "Round 3").
+# Round 3 replaced the additive "MFMA time + VALU time" model: PMC passes of tools/ubench/spec2 show that a
+# v_mfma_f32_16x16x32_f16 holds the VALU issue path for ~9.6 of its 16 matrix-pipe cycles (SQ_ACTIVE_INST_VALU counts 2.4
+# quad-cycles per MFMA), and tools/ubench/bank shows what the VALU classes cost at 3-4 waves/SIMD: plain VOP3 2.56, VOP2
+# 2.14, packed-f32 / converting 4.29, a transcendental 8.1 in a pure stream but ~11 between plain instructions (the
+# sigmoid chains exp -> add -> rcp -> mul measure 10.5 batched, 11.4 unit by unit).
+COST = {"v_mfma_f32_16x16x32_f16": 9.6, "v_mfma_f32_16x16x4_f32": 19.2, "v_mfma_f32_32x32x16_f16": 19.2,
+        "v_exp_f32": 11.0, "v_rcp_f32": 11.0, "v_log_f32": 11.0, "v_sqrt_f32": 11.0, "v_sin_f32": 11.0, "v_cos_f32": 11.0,
+        "v_rsq_f32": 11.0, "v_exp_f16": 11.0, "v_rcp_f16": 11.0,
+        "v_cvt_pk_f16_f32": 4.29, "v_cvt_pkrtz_f16_f32": 4.4, "v_perm_b32": 4.3, "v_cvt_f32_f16": 4.2,
+        "v_fma_mix_f32": 7.3, "v_fma_mixlo_f16": 7.3, "v_fma_mixhi_f16": 7.3,
+        "v_mul_f32": 2.14, "v_add_f32": 2.14, "v_sub_f32": 2.14, "v_permlane32_swap_b32": 8.2, "v_permlane16_swap_b32": 8.2}
+PK = 4.29     # v_pk_{fma,mul,add}_f32
+PLAIN = 2.56  # any other VALU
+MATRIX_PIPE = {"v_mfma_f32_16x16x32_f16": 16.2, "v_mfma_f32_16x16x4_f32": 32.0, "v_mfma_f32_32x32x16_f16": 32.1}  # matrix-pipe cycles
 
 
 def cost(m):
@@ -93,6 +100,12 @@ def profile(out_path):
                         "-Wno-pass-failed", "-Wno-unused-command-line-argument", "-I", os.path.join(root, "include"),
                         os.path.join(root, "bsdf_diffusion_sampling_amd", "csrc", "bsdfd.hip"), "-o", asm], check=True)
         res = {w: model(asm, k) for w, k in KERNEL_OF_WORKLOAD.items()}
+    import hashlib
+    src = os.path.join(root, "bsdf_diffusion_sampling_amd", "csrc", "bsdfd.hip")
+    git = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = bool(subprocess.run(["git", "-C", root, "status", "--porcelain", "--", src], capture_output=True, text=True).stdout.strip())
+    res["_meta"] = {"kernel_source_sha256": hashlib.sha256(open(src, "rb").read()).hexdigest(), "git": git + ("+dirty" if dirty else ""),
+                    "tool": "tools/isa_mix.py --profile", "cost_model": "VALU-issue-path occupancy, round 3 (see COST in tools/isa_mix.py)"}
     json.dump(res, open(out_path, "w"), indent=1)
     print(f"wrote {out_path}")
 
@@ -139,9 +152,11 @@ def model(path, key):
         "other": other,
         "issue_cycles_mfma": round(sum(cost(k) * v for k, v in mfma.items()), 1),
         "issue_cycles_valu": round(sum(cost(k) * v for k, v in valu.items()), 1),
+        "matrix_pipe_cycles": round(sum(MATRIX_PIPE.get(k, 16.2) * v for k, v in mfma.items()), 1),
         "meta": meta,
     }
-    res["issue_cycles_total"] = round(res["issue_cycles_mfma"] + res["issue_cycles_valu"], 1)
+    # the step is bound by the VALU issue path (MFMA issue occupancy + VALU), never by the matrix pipe itself here
+    res["issue_cycles_total"] = round(max(res["issue_cycles_mfma"] + res["issue_cycles_valu"], res["matrix_pipe_cycles"]), 1)
     return res
 
 

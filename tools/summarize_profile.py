@@ -74,7 +74,17 @@ def main():
     if os.path.exists(lp):
         latest = json.load(open(lp))
     if "hbm_bytes_per_launch" in out:
-        latest[workload] = {"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "source": f"{name}_pmc.json"}
+        import hashlib
+        import subprocess
+        kernel_src = os.path.join(ROOT, "bsdf_diffusion_sampling_amd", "csrc", "bsdfd.hip")
+        sha = hashlib.sha256(open(kernel_src, "rb").read()).hexdigest()
+        git = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        meta = latest.get("_meta", {})
+        if meta.get("kernel_source_sha256") != sha:   # entries of an older kernel do not survive next to new ones
+            latest = {}
+        latest["_meta"] = {"kernel_source_sha256": sha, "git": git, "tool": "tools/profile.sh + tools/summarize_profile.py"}
+        latest[workload] = {"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "source": f"{name}_pmc.json",
+                            "hbm_fetch_bytes_corrected": out["hbm_fetch_bytes_corrected"], "hbm_write_bytes": out["hbm_write_bytes"]}
         json.dump(latest, open(lp, "w"), indent=1)
     print(json.dumps(out, indent=1)[:3000])
 
