@@ -65,7 +65,7 @@ constexpr int MAX_SEG = 64;  // materials per segmented launch (the descriptors 
 enum { IO_OPERATOR = 0, IO_PLUGIN = 1, IO_PLUGIN_FULLSPHERE = 2 };
 
 struct ImgLayout {  // byte offsets into the weight image (identical in global memory and LDS)
-    int win, wc, wh, wh_lo, wo, wf, wf_lo, bw1, bb1, bw2, bb2, total;
+    int win, wc, wh, wh_lo, wo, wf, wf_lo, wg, wg_lo, bw1, bb1, bw2, bb2, total;
 };
 
 struct KParams {
@@ -175,6 +175,15 @@ __device__ __forceinline__ void sincos_enc(float a, float& s, float& c) {
 __device__ __forceinline__ void lds_read_b128_async(f16x8& dst, const char* p) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"((unsigned)(uintptr_t)p) : "memory");
 }
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128_async_at(f16x8& dst, unsigned lane_base) {  // address = lane_base + OFF (immediate)
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lane_base), "n"(OFF) : "memory");
+}
+// (one wait statement names every destination of a batch as "+v": all consumers are ordered behind it)
+#define BSDFD_WAIT2(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory")
+#define BSDFD_WAIT4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory")
+#define BSDFD_WAIT5(a, b, c, d, e) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : : "memory")
+#define BSDFD_WAIT6(a, b, c, d, e, f) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : : "memory")
 __device__ __forceinline__ void lds_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
 }
@@ -319,7 +328,12 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
     // fragments, live in the first hidden layer only) from LDS at the top of every step with asynchronous reads: no
     // scratch, traffic 1.0x, -3.7 % kernel time (profiles/r02_ab/ab7c: foldA = all resident, pin2 = this; letting the
     // compiler place those 4 reads costs another 2 % — it puts them right in front of their MFMAs).
-    constexpr bool PIN = FOLD_L1 && !FUSED && KC == 1;
+#ifdef BSDFD_X_MIM
+    constexpr bool MIM = FOLD_L1 && KC == 1 && !FUSED;
+#else
+    constexpr bool MIM = false;
+#endif
+    constexpr bool PIN = FOLD_L1 && !FUSED && KC == 1 && !MIM;
     f16x8 P_wh[2][NM], P_wl[2][NM], P_wo, P_f0h[NM], P_f1h[NM];
     if (PIN) {
         const int ln = threadIdx.x & 63;
@@ -583,7 +597,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             // VGPRs, no scratch, traffic 1.0x, +0.9 % kernel time (profiles/r02_ab/ab2: variant r32, sph8).  The disk
             // kernel has no spills and keeps its fragments in registers (the same change costs it 2 %).  The depth-unrolled
             // 64 x 6 kernels could not hold 5 layers of 64-wide fragments in registers at all: same treatment.
-            if ((DOMAIN == BSDFD_DOMAIN_SPHERICAL && ((NM == 2 && NH == 4 && JAC) || (NM == 4 && NH == 6))) || (FOLD_L1 && FUSED))
+            if ((DOMAIN == BSDFD_DOMAIN_SPHERICAL && ((NM == 2 && NH == 4 && JAC) || (NM == 4 && NH == 6))) || (FOLD_L1 && FUSED) || MIM)
                 asm volatile("");  // (the fused sample+pdf disk kernel carries more live state than PIN below can make room for)
             // PIN: the folded LO fragments of this step, requested now, consumed ~400 cycles later (first hidden layer)
             f16x8 pin_f0l[NM], pin_f1l[NM];
@@ -675,6 +689,188 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                             }
                         }
                     }
+                }
+            } else if (MIM) {
+                // ---- disk 25-32-32-32-2 nets: the 2x2 Jacobian by MEETING IN THE MIDDLE -------------------------------
+                // J = Wout D3 W3 D2 W2 D1 W1[:, :2] (D_l = diag silu'(z_l)).  Forward mode carries two tangent vectors
+                // through every layer: each needs a scaling by silu', a hi/lo split and its share of the MFMAs.  Here the
+                // input side is folded as before (U_i = W2 D1 W1[:, i] = F_i g1, F_i = W2 diag(W1[:, i]) packed by the host)
+                // and the OUTPUT side the same way, transposed: R_j = (Wout D3 W3)^T[:, j] = G_j g3 with
+                // G_j = W3^T diag(Wout[j, :]).  Both are plain matrix x vector contractions of the per-unit factors g1, g3;
+                // the middle factor D2 is applied in fp32: J_ji = sum_k R_j[k] g2[k] U_i[k].  Per step: 5 vectors split
+                // instead of 8, no tangent scalings, 38 fp16 MFMAs instead of 42; the price is the 2x2 bilinear form
+                // (24 packed FMAs) and one cross-lane reduction over the 4 lanes of a query (5 v_permlane swaps).
+                constexpr bool SPLIT = (PREC == BSDFD_PREC_SPLIT3);
+                // Weight fragments: 25 per step (W2, W3 hi/lo, Wout, F_0, F_1, G_0, G_1 hi/lo).  They do not fit the register
+                // budget of 3 waves/SIMD next to the flow state, so each layer's fragments are requested from LDS with
+                // asynchronous reads one phase ahead (while the previous layer's MFMAs / this layer's activation math run)
+                // and waited for once, right before the layer's first MFMA.  The image layout of this instantiation is a
+                // compile-time constant (build_image checks it), so every read is `lane base + immediate offset`.
+                constexpr int FR = 64 * 16;                                         // bytes of one fragment
+                constexpr int O_WH = NM * 64 * 4 + NM * PE_SLABS * 64 * 4;          // L.wh
+                constexpr int O_WHL = O_WH + (NH - 1) * NM * FR;                    // L.wh_lo (split3)
+                constexpr int O_WO = SPLIT ? O_WHL + (NH - 1) * NM * FR : O_WHL;    // L.wo
+                constexpr int O_WF = O_WO + FR;                                     // L.wf
+                constexpr int O_WFL = O_WF + 2 * NM * FR;                           // L.wf_lo
+                constexpr int O_WG = SPLIT ? O_WFL + 2 * NM * FR : O_WFL;           // L.wg
+                constexpr int O_WGL = O_WG + 2 * NM * FR;                           // L.wg_lo
+                const unsigned lb = (unsigned)(uintptr_t)smem + (unsigned)lane * 16u;
+                float hv[NM][4], gv[NM][4];
+                Frag bh, bl, gh, gl;
+                // -- hidden layer 1 -> z2, U0, U1
+                f16x8 w2h[NM], w2l[NM], f0h[NM], f1h[NM], f0l[NM], f1l[NM];
+                lds_read_b128_async_at<O_WH>(w2h[0], lb); lds_read_b128_async_at<O_WH + FR>(w2h[1], lb);
+                lds_read_b128_async_at<O_WF>(f0h[0], lb); lds_read_b128_async_at<O_WF + FR>(f0h[1], lb);
+                lds_read_b128_async_at<O_WF + 2 * FR>(f1h[0], lb); lds_read_b128_async_at<O_WF + 3 * FR>(f1h[1], lb);
+                if (SPLIT) {
+                    lds_read_b128_async_at<O_WHL>(w2l[0], lb); lds_read_b128_async_at<O_WHL + FR>(w2l[1], lb);
+                    lds_read_b128_async_at<O_WFL>(f0l[0], lb); lds_read_b128_async_at<O_WFL + FR>(f0l[1], lb);
+                    lds_read_b128_async_at<O_WFL + 2 * FR>(f1l[0], lb); lds_read_b128_async_at<O_WFL + 3 * FR>(f1l[1], lb);
+                }
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) silu_grad_scaled(z[m][r], hv[m][r], gv[m][r]);
+                    split_pack<SPLIT>(hv[m], bh.p[2 * m], bh.p[2 * m + 1], bl.p[2 * m], bl.p[2 * m + 1]);
+                    split_pack<SPLIT>(gv[m], gh.p[2 * m], gh.p[2 * m + 1], gl.p[2 * m], gl.p[2 * m + 1]);
+                }
+                BSDFD_WAIT6(w2h[0], w2h[1], f0h[0], f0h[1], f1h[0], f1h[1]);
+                if (SPLIT) BSDFD_WAIT6(w2l[0], w2l[1], f0l[0], f0l[1], f1l[0], f1l[1]);
+                // next layer's fragments: in flight during this layer's MFMAs and the next activation math
+                f16x8 w3h[NM], w3l[NM];
+                lds_read_b128_async_at<O_WH + 2 * FR>(w3h[0], lb); lds_read_b128_async_at<O_WH + 3 * FR>(w3h[1], lb);
+                if (SPLIT) { lds_read_b128_async_at<O_WHL + 2 * FR>(w3l[0], lb); lds_read_b128_async_at<O_WHL + 3 * FR>(w3l[1], lb); }
+                // z2 first (the next activation needs nothing else); the 12 MFMAs of U0, U1 are off the critical path — J is
+                // formed at the end of the step — so they run in the matrix pipe under the next layer's activation math
+                f32x4 U0[NM], U1[NM];
+#pragma unroll
+                for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(w2h[mo], bh.v, zero4);
+                if (SPLIT) {
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(w2h[mo], bl.v, z[mo]);
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(w2l[mo], bh.v, z[mo]);
+                }
+#pragma unroll
+                for (int mo = 0; mo < NM; ++mo) {
+                    U0[mo] = mfma16(f0h[mo], gh.v, zero4);
+                    U1[mo] = mfma16(f1h[mo], gh.v, zero4);
+                }
+                if (SPLIT) {
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) {
+                        U0[mo] = mfma16(f0h[mo], gl.v, U0[mo]);
+                        U1[mo] = mfma16(f1h[mo], gl.v, U1[mo]);
+                    }
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) {
+                        U0[mo] = mfma16(f0l[mo], gh.v, U0[mo]);
+                        U1[mo] = mfma16(f1l[mo], gh.v, U1[mo]);
+                    }
+                }
+                // -- hidden layer 2 -> z3 (its silu' stays in fp32: the middle factor of J)
+                float g2[NM][4];
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) silu_grad_scaled(z[m][r], hv[m][r], g2[m][r]);
+                    split_pack<SPLIT>(hv[m], bh.p[2 * m], bh.p[2 * m + 1], bl.p[2 * m], bl.p[2 * m + 1]);
+                }
+                if (SPLIT) BSDFD_WAIT4(w3h[0], w3h[1], w3l[0], w3l[1]); else BSDFD_WAIT2(w3h[0], w3h[1]);
+                f16x8 wo, g0h[NM], g1h[NM], g0l[NM], g1l[NM];
+                lds_read_b128_async_at<O_WO>(wo, lb);
+                lds_read_b128_async_at<O_WG>(g0h[0], lb); lds_read_b128_async_at<O_WG + FR>(g0h[1], lb);
+                lds_read_b128_async_at<O_WG + 2 * FR>(g1h[0], lb); lds_read_b128_async_at<O_WG + 3 * FR>(g1h[1], lb);
+                if (SPLIT) {
+                    lds_read_b128_async_at<O_WGL>(g0l[0], lb); lds_read_b128_async_at<O_WGL + FR>(g0l[1], lb);
+                    lds_read_b128_async_at<O_WGL + 2 * FR>(g1l[0], lb); lds_read_b128_async_at<O_WGL + 3 * FR>(g1l[1], lb);
+                }
+#pragma unroll
+                for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(w3h[mo], bh.v, zero4);
+                if (SPLIT) {
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(w3h[mo], bl.v, z[mo]);
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(w3l[mo], bh.v, z[mo]);
+                }
+                // -- hidden layer 3 -> v, R0, R1
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) silu_grad_scaled(z[m][r], hv[m][r], gv[m][r]);
+                    split_pack<SPLIT>(hv[m], bh.p[2 * m], bh.p[2 * m + 1], bl.p[2 * m], bl.p[2 * m + 1]);
+                    split_pack<SPLIT>(gv[m], gh.p[2 * m], gh.p[2 * m + 1], gl.p[2 * m], gl.p[2 * m + 1]);
+                }
+                BSDFD_WAIT5(wo, g0h[0], g0h[1], g1h[0], g1h[1]);
+                if (SPLIT) BSDFD_WAIT4(g0l[0], g0l[1], g1l[0], g1l[1]);
+                f32x4 R0[NM], R1[NM];
+                {
+                    f32x4 e = mfma16(wo, bh.v, zero4);
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) {
+                        R0[mo] = mfma16(g0h[mo], gh.v, zero4);
+                        R1[mo] = mfma16(g1h[mo], gh.v, zero4);
+                    }
+                    if (SPLIT) {
+                        e = mfma16(wo, bl.v, e);
+#pragma unroll
+                        for (int mo = 0; mo < NM; ++mo) {
+                            R0[mo] = mfma16(g0h[mo], gl.v, R0[mo]);
+                            R1[mo] = mfma16(g1h[mo], gl.v, R1[mo]);
+                        }
+#pragma unroll
+                        for (int mo = 0; mo < NM; ++mo) {
+                            R0[mo] = mfma16(g0l[mo], gh.v, R0[mo]);
+                            R1[mo] = mfma16(g1l[mo], gh.v, R1[mo]);
+                        }
+                    }
+                    v[0] = e[0] + e[2]; v[1] = e[1] + e[3];
+                }
+                // -- J_ji = sum_k R_j[k] g2[k] U_i[k]: this lane's 8 units, then the 4 lanes (g) of the query
+                // (element pairs: the compiler emits v_pk_mul_f32 / v_pk_fma_f32 for the 2-vectors)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 ja2 = {0.f, 0.f}, jb2 = ja2, jc2 = ja2, jd2 = ja2;  // J00, J11, J01, J10
+#pragma unroll
+                for (int m = 0; m < NM; ++m)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x2 gg2 = {g2[m][2 * h], g2[m][2 * h + 1]};
+                        const f32x2 r0 = {R0[m][2 * h], R0[m][2 * h + 1]}, r1 = {R1[m][2 * h], R1[m][2 * h + 1]};
+                        const f32x2 u0 = gg2 * (f32x2){U0[m][2 * h], U0[m][2 * h + 1]};
+                        const f32x2 u1 = gg2 * (f32x2){U1[m][2 * h], U1[m][2 * h + 1]};
+                        ja2 = __builtin_elementwise_fma(r0, u0, ja2);
+                        jc2 = __builtin_elementwise_fma(r0, u1, jc2);
+                        jd2 = __builtin_elementwise_fma(r1, u0, jd2);
+                        jb2 = __builtin_elementwise_fma(r1, u1, jb2);
+                    }
+                float ja = ja2[0] + ja2[1], jb = jb2[0] + jb2[1], jc = jc2[0] + jc2[1], jd = jd2[0] + jd2[1];
+                {
+                    // v_permlane32_swap(x, y): x[32..63] <-> y[0..31]; afterwards x + y holds, in the lower half-wave, x summed
+                    // over the lane pairs (l, l + 32) and, in the upper half, y summed over them.  v_permlane16_swap does the
+                    // same between the odd 16-lane rows of x and the even rows of y.  Two levels leave J00 | J01 | J11 | J10 in
+                    // rows 0 | 1 | 2 | 3 (row = g = lane >> 4), each summed over the query's 4 lanes.
+                    auto swap32 = [](float& x, float& y) {
+                        const auto t_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+                        x = __uint_as_float(t_[0]); y = __uint_as_float(t_[1]);
+                    };
+                    auto swap16 = [](float& x, float& y) {
+                        const auto t_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+                        x = __uint_as_float(t_[0]); y = __uint_as_float(t_[1]);
+                    };
+                    swap32(ja, jb);
+                    float sab = ja + jb;        // rows 0,1: J00 over (g, g+2) | rows 2,3: J11 over (g-2, g)
+                    swap32(jc, jd);
+                    float scd = jc + jd;        // rows 0,1: J01 | rows 2,3: J10
+                    swap16(sab, scd);
+                    const float tj = sab + scd; // row 0: J00, row 1: J01, row 2: J11, row 3: J10
+                    // w = 1 + c J on the diagonal rows (0, 2), c J on the others; det = w0 w2 - w1 w3 (mlp_brdf_sampling.py:44-46)
+                    float w = fmaf(cstep, tj, (g & 1) ? 0.0f : 1.0f), w2 = w;
+                    swap32(w, w2);              // w: rows (0,1,0,1) of the old w, w2: rows (2,3,2,3)
+                    float pr = w * w2, pr2 = pr;  // row 0: w0 w2, row 1: w1 w3
+                    swap16(pr, pr2);            // pr row 0 = old row 0, pr2 row 0 = old row 1
+                    const float det = pr - pr2; // valid in row 0 (g == 0), the lane that writes the query's results
+                    // forward: the reference divides (tmp_J /= J); v_rcp_f32 (1 ulp) * acc differs from the IEEE quotient by <= 2 ulp
+                    if (reverse) acc *= det; else acc *= __builtin_amdgcn_rcpf(det);
                 }
             } else {
                 // ---- fp16 MFMA path ----
@@ -819,7 +1015,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             }
 
             // det(I + c*J) with the row convention of mlp_brdf_sampling.py:44-46; signed.
-            if (JAC) {
+            if (JAC && !MIM) {
                 const float j00 = 1.0f + cstep * d0[0];
                 const float j01 = cstep * d1[0];
                 const float j10 = cstep * d0[1];
@@ -961,14 +1157,32 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
         if (prec == BSDFD_PREC_SPLIT3) off += (NH - 1) * NM * KC * 64 * 16;
         L.wo = off; off += KC * 64 * 16;
     }
-    L.wf = L.wf_lo = 0;
+    L.wf = L.wf_lo = L.wg = L.wg_lo = 0;
     // folded layer-1 tangent matrices W2 diag(W1[:, i]), i = 0, 1, of the disk nets (FOLD_L1 in the kernel)
     const bool fold = d.domain == BSDFD_DOMAIN_DISK && prec != BSDFD_PREC_F32 && NH >= 2 && NM == 2;
     const int NFOLD = 2;
+    // ... and, for the 3-hidden-layer disk nets, the output side folded the same way (MIM in the kernel):
+    // G_j = W3^T diag(Wout[j, :]), j = 0, 1, so that (Wout D3 W3)^T[:, j] = G_j g3
+    const bool mim = fold && NH == 3;
     if (fold) {
         L.wf = off; off += NFOLD * NM * KC * 64 * 16;
         L.wf_lo = off;
         if (prec == BSDFD_PREC_SPLIT3) off += NFOLD * NM * KC * 64 * 16;
+    }
+    if (mim) {
+        L.wg = off; off += NFOLD * NM * KC * 64 * 16;
+        L.wg_lo = off;
+        if (prec == BSDFD_PREC_SPLIT3) off += NFOLD * NM * KC * 64 * 16;
+        // the MIM kernel addresses its fragments with compile-time offsets: keep the two in step
+        const int fr = 64 * 16, o_wh = NM * 64 * 4 + NM * PE_SLABS * 64 * 4, o_whl = o_wh + (NH - 1) * NM * fr;
+        const bool sp = prec == BSDFD_PREC_SPLIT3;
+        const int o_wo = sp ? o_whl + (NH - 1) * NM * fr : o_whl, o_wf = o_wo + fr, o_wfl = o_wf + 2 * NM * fr;
+        const int o_wg = sp ? o_wfl + 2 * NM * fr : o_wfl, o_wgl = o_wg + 2 * NM * fr;
+        if (L.wh != o_wh || L.wh_lo != (sp ? o_whl : o_wh) || L.wo != o_wo || L.wf != o_wf || L.wf_lo != o_wfl || L.wg != o_wg ||
+            L.wg_lo != o_wgl) {
+            std::fprintf(stderr, "bsdfd: weight-image layout drifted from the kernel's compile-time offsets\n");
+            std::abort();
+        }
     }
     L.bw1 = off; off += (BASE_PE_BANDS + 1) * 64 * 4;
     L.bb1 = off; off += 64 * 16;
@@ -1041,6 +1255,21 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
                                 const float hi = f16_round((float)v);
                                 H(L.wf)[idx] = f32_to_f16_bits((float)v);
                                 if (prec == BSDFD_PREC_SPLIT3) H(L.wf_lo)[idx] = f32_to_f16_bits((float)(v - (double)hi));
+                            }
+        if (mim)
+            for (int i = 0; i < NFOLD; ++i)
+                for (int mo = 0; mo < NM; ++mo)
+                    for (int kc = 0; kc < KC; ++kc)
+                        for (int l = 0; l < 64; ++l)
+                            for (int j = 0; j < 8; ++j) {
+                                const int k = 16 * (2 * kc + (j >> 2)) + 4 * (l >> 4) + (j & 3);  // layer-3 unit (contraction index)
+                                const int unit = 16 * mo + (l & 15);                                // layer-2 unit (row of G_i)
+                                // G_i[unit][k] = W3[k][unit] * Wout[i][k], Wout already scaled by -ln 2 (d.w_out)
+                                const double v = (double)d.w_hidden[((size_t)1 * W + k) * W + unit] * (double)d.w_out[(size_t)i * W + k];
+                                const size_t idx = ((((size_t)i * NM + mo) * KC + kc) * 64 + l) * 8 + j;
+                                const float hi = f16_round((float)v);
+                                H(L.wg)[idx] = f32_to_f16_bits((float)v);
+                                if (prec == BSDFD_PREC_SPLIT3) H(L.wg_lo)[idx] = f32_to_f16_bits((float)(v - (double)hi));
                             }
         for (int kc = 0; kc < KC; ++kc)
             for (int l = 0; l < 64; ++l)
