@@ -179,11 +179,15 @@ template <int OFF>
 __device__ __forceinline__ void lds_read_b128_async_at(f16x8& dst, unsigned lane_base) {  // address = lane_base + OFF (immediate)
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lane_base), "n"(OFF) : "memory");
 }
-// (one wait statement names every destination of a batch as "+v": all consumers are ordered behind it)
-#define BSDFD_WAIT2(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory")
-#define BSDFD_WAIT4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory")
-#define BSDFD_WAIT5(a, b, c, d, e) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : : "memory")
-#define BSDFD_WAIT6(a, b, c, d, e, f) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : : "memory")
+// One wait statement names every destination of a batch as "+v": all consumers are ordered behind it.  `after` is a value
+// the wait is made to depend on as well (the B fragment the activation math of the layer produces): without it the compiler
+// schedules the wait — which depends on nothing else — right behind the reads, in front of the math that is meant to hide them.
+#define BSDFD_WAIT2(after, a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(after), "+v"(a), "+v"(b) : : "memory")
+#define BSDFD_WAIT4(after, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(after), "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory")
+#define BSDFD_WAIT5(after, a, b, c, d, e) \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(after), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : : "memory")
+#define BSDFD_WAIT6(after, a, b, c, d, e, f) \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(after), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : : "memory")
 __device__ __forceinline__ void lds_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
 }
@@ -734,8 +738,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                     split_pack<SPLIT>(hv[m], bh.p[2 * m], bh.p[2 * m + 1], bl.p[2 * m], bl.p[2 * m + 1]);
                     split_pack<SPLIT>(gv[m], gh.p[2 * m], gh.p[2 * m + 1], gl.p[2 * m], gl.p[2 * m + 1]);
                 }
-                BSDFD_WAIT6(w2h[0], w2h[1], f0h[0], f0h[1], f1h[0], f1h[1]);
-                if (SPLIT) BSDFD_WAIT6(w2l[0], w2l[1], f0l[0], f0l[1], f1l[0], f1l[1]);
+                BSDFD_WAIT6(gh.v, w2h[0], w2h[1], f0h[0], f0h[1], f1h[0], f1h[1]);
+                if (SPLIT) BSDFD_WAIT6(gl.v, w2l[0], w2l[1], f0l[0], f0l[1], f1l[0], f1l[1]);
                 // next layer's fragments: in flight during this layer's MFMAs and the next activation math
                 f16x8 w3h[NM], w3l[NM];
                 lds_read_b128_async_at<O_WH + 2 * FR>(w3h[0], lb); lds_read_b128_async_at<O_WH + 3 * FR>(w3h[1], lb);
@@ -776,7 +780,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                     for (int r = 0; r < 4; ++r) silu_grad_scaled(z[m][r], hv[m][r], g2[m][r]);
                     split_pack<SPLIT>(hv[m], bh.p[2 * m], bh.p[2 * m + 1], bl.p[2 * m], bl.p[2 * m + 1]);
                 }
-                if (SPLIT) BSDFD_WAIT4(w3h[0], w3h[1], w3l[0], w3l[1]); else BSDFD_WAIT2(w3h[0], w3h[1]);
+                if (SPLIT) BSDFD_WAIT4(bl.v, w3h[0], w3h[1], w3l[0], w3l[1]); else BSDFD_WAIT2(bh.v, w3h[0], w3h[1]);
                 f16x8 wo, g0h[NM], g1h[NM], g0l[NM], g1l[NM];
                 lds_read_b128_async_at<O_WO>(wo, lb);
                 lds_read_b128_async_at<O_WG>(g0h[0], lb); lds_read_b128_async_at<O_WG + FR>(g0h[1], lb);
@@ -801,8 +805,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                     split_pack<SPLIT>(hv[m], bh.p[2 * m], bh.p[2 * m + 1], bl.p[2 * m], bl.p[2 * m + 1]);
                     split_pack<SPLIT>(gv[m], gh.p[2 * m], gh.p[2 * m + 1], gl.p[2 * m], gl.p[2 * m + 1]);
                 }
-                BSDFD_WAIT5(wo, g0h[0], g0h[1], g1h[0], g1h[1]);
-                if (SPLIT) BSDFD_WAIT4(g0l[0], g0l[1], g1l[0], g1l[1]);
+                BSDFD_WAIT5(gh.v, wo, g0h[0], g0h[1], g1h[0], g1h[1]);
+                if (SPLIT) BSDFD_WAIT4(gl.v, g0l[0], g0l[1], g1l[0], g1l[1]);
                 f32x4 R0[NM], R1[NM];
                 {
                     f32x4 e = mfma16(wo, bh.v, zero4);
