@@ -169,12 +169,10 @@ __device__ __forceinline__ void sincos_enc(float a, float& s, float& c) {
     else sincosf(a, &s, &c);
 }
 
-// LDS reads the compiler does not schedule or wait for: issued early (top of an Euler step) and waited for just before
-// the first MFMA that consumes them; the wait statement names every destination as "+v", which orders all consumers
-// behind it (cdna_hip_programming.md §5.7, form (ii)).  hipcc itself places a ds_read right in front of its use.
-__device__ __forceinline__ void lds_read_b128_async(f16x8& dst, const char* p) {
-    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"((unsigned)(uintptr_t)p) : "memory");
-}
+// LDS reads the compiler does not schedule or wait for: issued a phase ahead of their use and waited for just before the
+// first MFMA that consumes them (cdna_hip_programming.md §5.7, form (ii)).  hipcc itself places a ds_read right in front of
+// its use.  Until the wait statement the destination registers hold stale data although the compiler considers them defined:
+// tools/isa_mix.py --check-async verifies on the built assembly that nothing touches them in between.
 template <int OFF>
 __device__ __forceinline__ void lds_read_b128_async_at(f16x8& dst, unsigned lane_base) {  // address = lane_base + OFF (immediate)
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lane_base), "n"(OFF) : "memory");
@@ -188,10 +186,6 @@ __device__ __forceinline__ void lds_read_b128_async_at(f16x8& dst, unsigned lane
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(after), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : : "memory")
 #define BSDFD_WAIT6(after, a, b, c, d, e, f) \
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(after), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : : "memory")
-__device__ __forceinline__ void lds_wait4(f16x8& a, f16x8& b, f16x8& c, f16x8& d) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
-}
-
 union Frag {  // one MFMA B fragment: the lane's 8 K-values of a chunk
     f16x8 v;
     f16x2 p[4];
@@ -326,36 +320,13 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
     // (three folded matrices, d/dphi = cos(phi) F_sin g - sin(phi) F_cos g: +6 fp16 MFMAs, -2 fp32 MFMAs, one split less)
     // was built and measured at +-0.2 %: not kept.
     constexpr bool FOLD_L1 = JAC && NM == 2 && PREC != BSDFD_PREC_F32 && DOMAIN == BSDFD_DOMAIN_DISK && NH == 3;
-    // With the folded matrices all register-resident the disk kernel wants 4 VGPRs more than 3 waves/SIMD allow (20 B/lane
-    // of scratch, HBM traffic 1.23x the algorithmic bytes; -5 % kernel time).  PIN: this kernel loads the fragments it
-    // keeps resident EXPLICITLY here (hidden layers, output layer, folded hi parts) and fetches the folded LO parts (4
-    // fragments, live in the first hidden layer only) from LDS at the top of every step with asynchronous reads: no
-    // scratch, traffic 1.0x, -3.7 % kernel time (profiles/r02_ab/ab7c: foldA = all resident, pin2 = this; letting the
-    // compiler place those 4 reads costs another 2 % — it puts them right in front of their MFMAs).
-#ifdef BSDFD_X_MIM
+    // MIM (same nets, single-op kernels): the OUTPUT side of the Jacobian is folded as well and the two halves meet in
+    // the middle — see the block in the Euler step.  The fused sample+pdf instantiation keeps the forward-mode tangents
+    // (its two-phase state leaves no room for the asynchronously fetched fragments: 9 spilled VGPRs when tried).
+    // History: with only the input side folded and every fragment register-resident the kernel wanted 4 VGPRs more than 3
+    // waves/SIMD allow; round 2 shipped a "PIN" arrangement (resident hi parts, the 4 folded lo fragments fetched
+    // asynchronously per step: -3.7 %); MIM supersedes it (-5.7 % on top, profiles/r03_ab/mim_*.txt).
     constexpr bool MIM = FOLD_L1 && KC == 1 && !FUSED;
-#else
-    constexpr bool MIM = false;
-#endif
-    constexpr bool PIN = FOLD_L1 && !FUSED && KC == 1 && !MIM;
-    f16x8 P_wh[2][NM], P_wl[2][NM], P_wo, P_f0h[NM], P_f1h[NM];
-    if (PIN) {
-        const int ln = threadIdx.x & 63;
-#pragma unroll
-        for (int l = 0; l < 2; ++l)
-#pragma unroll
-            for (int mo = 0; mo < NM; ++mo) {
-                const size_t off = (size_t)l * NM * KC * 64 * 16 + ((size_t)mo * 64 + ln) * 16;
-                P_wh[l][mo] = *reinterpret_cast<const f16x8*>(smem + p.L.wh + off);
-                if (PREC == BSDFD_PREC_SPLIT3) P_wl[l][mo] = *reinterpret_cast<const f16x8*>(smem + p.L.wh_lo + off);
-            }
-        P_wo = *reinterpret_cast<const f16x8*>(smem + p.L.wo + (size_t)ln * 16);
-#pragma unroll
-        for (int mo = 0; mo < NM; ++mo) {
-            P_f0h[mo] = *reinterpret_cast<const f16x8*>(smem + p.L.wf + ((size_t)mo * 64 + ln) * 16);
-            P_f1h[mo] = *reinterpret_cast<const f16x8*>(smem + p.L.wf + (size_t)NM * KC * 64 * 16 + ((size_t)mo * 64 + ln) * 16);
-        }
-    }
     const int n_hidden = NH ? NH : p.n_hidden;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4;
@@ -602,16 +573,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             // kernel has no spills and keeps its fragments in registers (the same change costs it 2 %).  The depth-unrolled
             // 64 x 6 kernels could not hold 5 layers of 64-wide fragments in registers at all: same treatment.
             if ((DOMAIN == BSDFD_DOMAIN_SPHERICAL && ((NM == 2 && NH == 4 && JAC) || (NM == 4 && NH == 6))) || (FOLD_L1 && FUSED) || MIM)
-                asm volatile("");  // (the fused sample+pdf disk kernel carries more live state than PIN below can make room for)
-            // PIN: the folded LO fragments of this step, requested now, consumed ~400 cycles later (first hidden layer)
-            f16x8 pin_f0l[NM], pin_f1l[NM];
-            if (PIN && PREC == BSDFD_PREC_SPLIT3) {
-#pragma unroll
-                for (int mo = 0; mo < NM; ++mo) {
-                    lds_read_b128_async(pin_f0l[mo], Lwf_lo + ((size_t)mo * 64 + lane) * 16);
-                    lds_read_b128_async(pin_f1l[mo], Lwf_lo + (size_t)NM * KC * 64 * 16 + ((size_t)mo * 64 + lane) * 16);
-                }
-            }
+                asm volatile("");  // (the fused sample+pdf disk kernel: same treatment; MIM fetches its fragments explicitly)
             // alpha = float32(t/T) resp. float32(1 - t/T) as torch forms them (python double, then
             // cast); t * (1/T) in fp64 differs from t/T by < 1 ulp(fp64), invisible after the cast.
             float alpha;
@@ -928,11 +890,6 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 #pragma unroll
                             for (int mo = 0; mo < NM; ++mo) {
                                 const size_t off = lbase + ((size_t)(mo * KC + kc) * 64 + lane) * 16;
-                                if (PIN) {
-                                    wh[mo] = P_wh[layer < 2 ? layer : 0][mo];
-                                    if (SPLIT) wl[mo] = P_wl[layer < 2 ? layer : 0][mo];
-                                    continue;
-                                }
                                 wh[mo] = *reinterpret_cast<const f16x8*>(Lwh + off);
                                 if (SPLIT) wl[mo] = *reinterpret_cast<const f16x8*>(Lwh_lo + off);
                             }
@@ -944,18 +901,12 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 #pragma unroll
                                 for (int mo = 0; mo < NM; ++mo) {
                                     const size_t foff = ((size_t)(mo * KC + kc) * 64 + lane) * 16;
-                                    f0h[mo] = PIN ? P_f0h[mo] : *reinterpret_cast<const f16x8*>(Lwf + foff);
-                                    f1h[mo] = PIN ? P_f1h[mo] : *reinterpret_cast<const f16x8*>(Lwf + fstride + foff);
+                                    f0h[mo] = *reinterpret_cast<const f16x8*>(Lwf + foff);
+                                    f1h[mo] = *reinterpret_cast<const f16x8*>(Lwf + fstride + foff);
                                     if (SPLIT) {
-                                        if (PIN) continue;
                                         f0l[mo] = *reinterpret_cast<const f16x8*>(Lwf_lo + foff);
                                         f1l[mo] = *reinterpret_cast<const f16x8*>(Lwf_lo + fstride + foff);
                                     }
-                                }
-                                if (PIN && SPLIT) {
-                                    lds_wait4(pin_f0l[0], pin_f0l[1 % NM], pin_f1l[0], pin_f1l[1 % NM]);
-#pragma unroll
-                                    for (int mo = 0; mo < NM; ++mo) { f0l[mo] = pin_f0l[mo]; f1l[mo] = pin_f1l[mo]; }
                                 }
 #pragma unroll
                                 for (int mo = 0; mo < NM; ++mo) {
@@ -1003,7 +954,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                         f32x4 e = zero4, e0 = zero4, e1 = zero4;
 #pragma unroll
                         for (int kc = 0; kc < KC; ++kc) {
-                            const f16x8 wo = PIN ? P_wo : *reinterpret_cast<const f16x8*>(Lwo + ((size_t)kc * 64 + lane) * 16);
+                            const f16x8 wo = *reinterpret_cast<const f16x8*>(Lwo + ((size_t)kc * 64 + lane) * 16);
                             e = mfma16(wo, bh[kc].v, e);
                             if (JAC) { e0 = mfma16(wo, b0h[kc].v, e0); e1 = mfma16(wo, b1h[kc].v, e1); }
                             if (SPLIT) {

@@ -331,3 +331,38 @@ def test_torch_operator_library_registers_every_operator():
         with pytest.raises(RuntimeError):
             ns.create_from_file("/nonexistent.bsdfw", 0, 0)
 
+
+
+def test_asynchronous_lds_reads_are_not_touched_before_their_wait():
+    """csrc/bsdfd.hip fetches weight fragments with inline-asm ds_read_b128 whose destination registers only become valid
+    at the following s_waitcnt (the compiler believes them valid at once).  tools/isa_mix.py --check-async verifies on the
+    assembly of THIS toolchain's build that nothing reads, writes or spills them in between (a different hipcc
+    could schedule a copy into that window)."""
+    import shutil
+    import subprocess
+    import sys
+    if not shutil.which("hipcc"):
+        pytest.skip("needs hipcc")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py"), "--check-async"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 violations" in r.stdout and "25 asynchronous" in r.stdout
+
+
+def test_committed_profiles_match_the_kernel_source():
+    """bench.py looks `roofline.traffic` (PMC passes) and the instruction-issue model (ISA of the build) up in profiles/*.json
+    and withholds them when csrc/bsdfd.hip has changed since they were taken ("a kernel change without a profile
+    refresh would silently carry stale figures").  The committed tree must never be in that state."""
+    import hashlib
+    import json
+    sha = hashlib.sha256(open(os.path.join(ROOT, "bsdf_diffusion_sampling_amd", "csrc", "bsdfd.hip"), "rb").read()).hexdigest()
+    for f in ("isa_mix_latest.json", "pmc_latest.json"):
+        meta = json.load(open(os.path.join(ROOT, "profiles", f))).get("_meta", {})
+        assert meta.get("kernel_source_sha256") == sha, f"profiles/{f} was taken with another csrc/bsdfd.hip: re-run tools/profile.sh / tools/isa_mix.py --profile"
+    sys.path.insert(0, ROOT)
+    import bench
+    for wl in ("disk_1Mi_T8", "spherical_16Mi_T8"):
+        entry, prov = bench.profile_lookup("pmc_latest.json", wl)
+        assert prov["status"] == "current" and entry["hbm_bytes_per_launch"] > 0
+        entry, prov = bench.isa_model(wl)
+        assert prov["status"] == "current" and entry["n_mfma"] > 0

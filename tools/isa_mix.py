@@ -110,9 +110,86 @@ def profile(out_path):
     print(f"wrote {out_path}")
 
 
+def _regs(tok):
+    """VGPR indices named by an operand token: v12 -> {12}, v[4:7] -> {4..7}."""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def check_async(path, key):
+    """The flow kernel fetches weight fragments with inline-asm `ds_read_b128` whose destinations the compiler believes valid
+    at once (csrc/bsdfd.hip, lds_read_b128_async_at); they are only valid after the next `s_waitcnt lgkmcnt(0)`.  Verify on the
+    built assembly that no instruction reads or writes a destination register in between, and that the kernel has no scratch
+    (a spill of such a register would store stale data).  Returns the list of violations (empty = safe)."""
+    lines = open(path).read().splitlines()
+    body = kernel_body(lines, key)
+    bad, pending, in_asm, n_async = [], {}, False, 0
+    for i, raw in enumerate(body):
+        l = raw.strip()
+        if l.startswith(";;#ASMSTART") or l.startswith(";#ASMSTART"):
+            in_asm = True
+            continue
+        if l.startswith(";;#ASMEND") or l.startswith(";#ASMEND"):
+            in_asm = False
+            continue
+        code = l.split(";")[0].strip()
+        if not code or code.endswith(":") or code.startswith("."):
+            continue
+        op = code.split()[0]
+        toks = [t.strip(",") for t in code.split()[1:]]
+        if op.startswith("s_waitcnt") and "lgkmcnt(0)" in code:
+            pending.clear()
+            continue
+        touched = set().union(*[_regs(t) for t in toks]) if toks else set()
+        for r in touched & set(pending):
+            bad.append(f"line {i}: `{code}` touches v{r}, the destination of the asynchronous read at line {pending[r]}")
+        if in_asm and op == "ds_read_b128":
+            n_async += 1
+            for r in _regs(toks[0]):
+                pending[r] = i
+        if op.startswith("s_cbranch") or op.startswith("s_branch") or op == "s_endpgm":
+            if pending:
+                bad.append(f"line {i}: control flow `{code}` with {len(pending)} asynchronous destination registers still pending")
+                pending.clear()
+    meta = {}
+    for i, l in enumerate(lines):
+        if ".name:" in l and key in l:
+            for l2 in lines[i:i + 16]:
+                m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", l2)
+                if m:
+                    meta["scratch"] = int(m.group(1))
+            break
+    if meta.get("scratch", 0) != 0:
+        bad.append(f"kernel uses {meta['scratch']} B/lane of scratch: a spilled asynchronous destination would be stale")
+    return n_async, bad
+
+
 def main():
     if sys.argv[1] == "--profile":
         return profile(sys.argv[2])
+    if sys.argv[1] == "--check-async":
+        import os
+        import subprocess
+        import tempfile
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        with tempfile.TemporaryDirectory() as td:
+            asm = os.path.join(td, "bsdfd.s")
+            subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-value",
+                            "-Wno-pass-failed", "-Wno-unused-command-line-argument", "-I", os.path.join(root, "include"),
+                            os.path.join(root, "bsdf_diffusion_sampling_amd", "csrc", "bsdfd.hip"), "-o", asm], check=True)
+            rc = 0
+            for key in ("flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E", "flow_kernelILi0ELi2ELi3ELb1ELi3ELb0E"):  # disk 32x3: split3, f16
+                n, bad = check_async(asm, key)
+                print(f"{key}: {n} asynchronous ds_read_b128, {len(bad)} violations")
+                for b in bad:
+                    print("  ", b)
+                rc |= bool(bad) or n == 0
+        return rc
     print(json.dumps(model(sys.argv[1], sys.argv[2]), indent=1))
 
 
@@ -161,4 +238,4 @@ def model(path, key):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)
