@@ -1348,16 +1348,10 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     const int mode = op == OP_SAMPLES_ONLY ? 0 : (op == OP_SAMPLE_PDF ? 2 : 1);
     int per_cu = h->per_cu[mode];
     if (per_cu < 1) per_cu = 1;
-#ifdef BSDFD_TUNING  // tools-only builds (tools/ab_build.sh ... "-DBSDFD_TUNING"): grid-shape knobs for tools/tscan.py, nscan.py
-    static const int per_cu_override = [] {
-        const char* ov = std::getenv("BSDFD_BLOCKS_PER_CU");
-        return ov ? std::atoi(ov) : 0;
-    }();
-    static const int cl_override = [] {
-        const char* ov = std::getenv("BSDFD_CHUNK_LOG2");
-        return ov ? std::atoi(ov) : -1;
-    }();
-    if (per_cu_override > 0) per_cu = per_cu_override;
+    // grid-shape overrides of the tools builds (tools/tuning_knobs.h, force-included by tools/ab_build.sh for tools/tscan.py
+    // and tools/nscan.py); the product build has none
+#ifdef BSDFD_TOOLS_KNOBS
+    BSDFD_TOOLS_KNOBS(per_cu)
 #else
     constexpr int cl_override = -1;
 #endif

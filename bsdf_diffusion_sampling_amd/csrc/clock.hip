@@ -60,11 +60,24 @@ extern "C" int bsdfd_shader_clock_mhz(double* mhz, void* hip_stream) {
     HIP_TRY(hipGetDeviceProperties(&prop, dev));
     unsigned long long* d_cyc = nullptr;
     float* d_sink = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_cyc), sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_sink), sizeof(float)));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    // one cleanup path for everything acquired here, whichever step fails
+    auto cleanup = [&] {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (d_cyc) (void)hipFree(d_cyc);
+        if (d_sink) (void)hipFree(d_sink);
+    };
+    {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_cyc), sizeof(unsigned long long));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_sink), sizeof(float));
+        if (e == hipSuccess) e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e != hipSuccess) {
+            cleanup();
+            return bsdfd_fail_(BSDFD_EHIP, std::string("clock probe: ") + hipGetErrorString(e));
+        }
+    }
     const int grid = prop.multiProcessorCount * 3;  // 3 workgroups of 4 waves per CU = the flow kernel's occupancy
     double best = 0.0;
     int rc = BSDFD_OK;
@@ -86,10 +99,7 @@ extern "C" int bsdfd_shader_clock_mhz(double* mhz, void* hip_stream) {
         if (e != hipSuccess) rc = bsdfd_fail_(BSDFD_EHIP, std::string("clock probe: ") + hipGetErrorString(e));
         else if (ms > 0.f) best = (double)cyc / ((double)ms * 1e3);  // cycles per microsecond = MHz
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipFree(d_cyc);
-    (void)hipFree(d_sink);
+    cleanup();
     *mhz = best;
     return rc;
 }

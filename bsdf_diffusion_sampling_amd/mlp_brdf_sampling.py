@@ -42,7 +42,11 @@ def _packed(D_base, D_sample, domain: int, precision: str) -> FlowSampler:
     # changes data_ptr), so a training loop that samples from a net it is updating (the reflow stage) never sees
     # stale packed weights; a frozen net costs one tuple of ~10 integers per call.
     def stamp(mod):
-        return tuple((k, v.data_ptr(), v._version) for k, v in mod.state_dict(keep_vars=True).items())
+        # named_parameters / named_buffers: no state_dict() is built per call (this path is host-bound at ~8 us)
+        return (id(mod),) + tuple((k, v.data_ptr(), v._version) for k, v in
+                                  list(mod.named_parameters(recurse=True)) + list(mod.named_buffers(recurse=True)))
+    # id(module) is part of the key: a REPLACED module or parameter whose storage reuses a freed address with the same
+    # version counter must not hit a stale entry (the cache lives on D_sample, so id(D_sample) is implied; D_base is not)
     key = (stamp(D_base), stamp(D_sample), domain, precision, torch.cuda.current_device())
     cache = D_sample.__dict__.setdefault("_bsdfd_cache", {})
     s = cache.get(key)

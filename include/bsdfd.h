@@ -207,7 +207,9 @@ int bsdfd_profile_read(bsdfd_handle h, int64_t* n_launches, double* total_ms);
 float bsdfd_last_kernel_ms(bsdfd_handle h);
 
 /* Shader clock (MHz) the chip sustains under the flow kernel's instruction mix: a ~6 ms probe launch on every
- * CU, shader-cycle counter of one wave / HIP-event duration (csrc/clock.hip).  Measurement only: bench.py
+ * CU, shader-cycle count of the LONGEST-lived wave (maximum over all waves) / HIP-event duration (csrc/clock.hip).
+ * The probe allocates, copies back and SYNCHRONISES: it must not be called while a stream is being captured
+ * (the rest of the API is capture-safe).  Measurement only: bench.py
  * uses it to state kernel time in shader cycles per (16-query tile x Euler step) next to the instruction-issue
  * model of that loop (the "issue-bound" roofline entry).  No counterpart in the reference. */
 int bsdfd_shader_clock_mhz(double* mhz, void* hip_stream);

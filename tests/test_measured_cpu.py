@@ -173,3 +173,18 @@ def test_native_loader_rejects_malformed_tensor_files(tmp_path):
     attempt(raw[: len(raw) // 2], "exceeds the file")                          # truncated payload
     attempt(raw[:40], "truncated header")
     attempt(b"not a tensor file at all", "not a tensor file")
+
+
+def test_against_mitsuba_measured_plugin_when_a_dump_exists(gt):
+    """tests/golden/make_mitsuba_golden.py writes `mitsuba_measured_eval.npz` on a machine where Mitsuba 3 is installed
+    (Mitsuba's `measured` plugin = what the reference's eval() delegates to, rendering/brdf_measured_disk.py:36-42,103-110).
+    No such machine has existed for this build, so this test SKIPS and SURVEY §8 row f3 stays parity-unpinned; the day the
+    file is committed the oracle is held to it."""
+    path = os.path.join(HERE, "golden", "mitsuba_measured_eval.npz")
+    if not os.path.exists(path):
+        pytest.skip("no Mitsuba dump (tests/golden/make_mitsuba_golden.py needs a machine with `pip install mitsuba`)")
+    d = np.load(path)
+    f = gt.eval(d["wi"].astype(np.float64), d["wo"].astype(np.float64))
+    ref = d["f_cos"].astype(np.float64)
+    scale = np.percentile(ref.max(1), 99)
+    assert np.percentile(np.abs(f - ref).max(1) / scale, 99) < 1e-3

@@ -1,4 +1,4 @@
-"""Per-query kernel time vs batch size (plugin-level pdf launches; BSDFD_CHUNK_LOG2 overrides the tile-chunk size in a tools build: tools/ab_build.sh tune "-DBSDFD_TUNING", BSDFD_LIB_PATH=build_ab/lib_tune.so)."""
+"""Per-query kernel time vs batch size (plugin-level pdf launches; BSDFD_CHUNK_LOG2 overrides the tile-chunk size in a tools build: tools/ab_build.sh tune "-include tools/tuning_knobs.h", BSDFD_LIB_PATH=build_ab/lib_tune.so)."""
 import sys, os, numpy as np, torch, time
 sys.path.insert(0,'.')
 from bsdf_diffusion_sampling_amd import weights as W, _lib
