@@ -327,6 +327,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
     // waves/SIMD allow; round 2 shipped a "PIN" arrangement (resident hi parts, the 4 folded lo fragments fetched
     // asynchronously per step: -3.7 %); MIM supersedes it (-5.7 % on top, profiles/r03_ab/mim_*.txt).
     constexpr bool MIM = FOLD_L1 && KC == 1 && !FUSED;
+    // the spherical 26-32x4-2 nets: two regular tangent layers, then the same meeting in the middle (block "MIMS" below)
+    constexpr bool MIMS = JAC && NM == 2 && PREC != BSDFD_PREC_F32 && DOMAIN == BSDFD_DOMAIN_SPHERICAL && NH == 4 && !FUSED;
     const int n_hidden = NH ? NH : p.n_hidden;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4;
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             // VGPRs, no scratch, traffic 1.0x, +0.9 % kernel time (profiles/r02_ab/ab2: variant r32, sph8).  The disk
             // kernel has no spills and keeps its fragments in registers (the same change costs it 2 %).  The depth-unrolled
             // 64 x 6 kernels could not hold 5 layers of 64-wide fragments in registers at all: same treatment.
-            if ((DOMAIN == BSDFD_DOMAIN_SPHERICAL && ((NM == 2 && NH == 4 && JAC) || (NM == 4 && NH == 6))) || (FOLD_L1 && FUSED) || MIM)
+            if ((DOMAIN == BSDFD_DOMAIN_SPHERICAL && ((NM == 2 && NH == 4 && JAC) || (NM == 4 && NH == 6))) || (FOLD_L1 && FUSED) || MIM || MIMS)
                 asm volatile("");  // (the fused sample+pdf disk kernel: same treatment; MIM fetches its fragments explicitly)
             // alpha = float32(t/T) resp. float32(1 - t/T) as torch forms them (python double, then
             // cast); t * (1/T) in fp64 differs from t/T by < 1 ulp(fp64), invisible after the cast.
@@ -607,6 +609,53 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             }
 
             f32x4 v = zero4, d0 = zero4, d1 = zero4;  // rows r=0,1: the two outputs
+            // MIM / MIMS: J_ji = sum_k R_j[k] gm[k] U_i[k] over this lane's 8 units, then over the 4 lanes (g) of the query; det
+            auto mim_finish = [&](const f32x4 (&R0)[NM], const f32x4 (&R1)[NM], const float (&gm)[NM][4], const f32x4 (&U0)[NM],
+                                  const f32x4 (&U1)[NM]) {
+                // (element pairs: the compiler emits v_pk_mul_f32 / v_pk_fma_f32 for the 2-vectors)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 ja2 = {0.f, 0.f}, jb2 = ja2, jc2 = ja2, jd2 = ja2;  // J00, J11, J01, J10
+#pragma unroll
+                for (int m = 0; m < NM; ++m)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x2 gg2 = {gm[m][2 * h], gm[m][2 * h + 1]};
+                        const f32x2 r0 = {R0[m][2 * h], R0[m][2 * h + 1]}, r1 = {R1[m][2 * h], R1[m][2 * h + 1]};
+                        const f32x2 u0 = gg2 * (f32x2){U0[m][2 * h], U0[m][2 * h + 1]};
+                        const f32x2 u1 = gg2 * (f32x2){U1[m][2 * h], U1[m][2 * h + 1]};
+                        ja2 = __builtin_elementwise_fma(r0, u0, ja2);
+                        jc2 = __builtin_elementwise_fma(r0, u1, jc2);
+                        jd2 = __builtin_elementwise_fma(r1, u0, jd2);
+                        jb2 = __builtin_elementwise_fma(r1, u1, jb2);
+                    }
+                float ja = ja2[0] + ja2[1], jb = jb2[0] + jb2[1], jc = jc2[0] + jc2[1], jd = jd2[0] + jd2[1];
+                // v_permlane32_swap(x, y): x[32..63] <-> y[0..31]; afterwards x + y holds, in the lower half-wave, x summed
+                // over the lane pairs (l, l + 32) and, in the upper half, y summed over them.  v_permlane16_swap does the
+                // same between the odd 16-lane rows of x and the even rows of y.  Two levels leave J00 | J01 | J11 | J10 in
+                // rows 0 | 1 | 2 | 3 (row = g = lane >> 4), each summed over the query's 4 lanes.
+                auto swap32 = [](float& x, float& y) {
+                    const auto t_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+                    x = __uint_as_float(t_[0]); y = __uint_as_float(t_[1]);
+                };
+                auto swap16 = [](float& x, float& y) {
+                    const auto t_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+                    x = __uint_as_float(t_[0]); y = __uint_as_float(t_[1]);
+                };
+                swap32(ja, jb);
+                float sab = ja + jb;        // rows 0,1: J00 over (g, g+2) | rows 2,3: J11 over (g-2, g)
+                swap32(jc, jd);
+                float scd = jc + jd;        // rows 0,1: J01 | rows 2,3: J10
+                swap16(sab, scd);
+                const float tj = sab + scd; // row 0: J00, row 1: J01, row 2: J11, row 3: J10
+                // w = 1 + c J on the diagonal rows (0, 2), c J on the others; det = w0 w2 - w1 w3 (mlp_brdf_sampling.py:44-46)
+                float w = fmaf(cstep, tj, (g & 1) ? 0.0f : 1.0f), w2 = w;
+                swap32(w, w2);              // w: rows (0,1,0,1) of the old w, w2: rows (2,3,2,3)
+                float pr = w * w2, pr2 = pr;  // row 0: w0 w2, row 1: w1 w3
+                swap16(pr, pr2);            // pr row 0 = old row 0, pr2 row 0 = old row 1
+                const float det = pr - pr2; // valid in row 0 (g == 0), the lane that writes the query's results
+                // forward: the reference divides (tmp_J /= J); v_rcp_f32 (1 ulp) * acc differs from the IEEE quotient by <= 2 ulp
+                if (reverse) acc *= det; else acc *= __builtin_amdgcn_rcpf(det);
+            };
             if (PREC == BSDFD_PREC_F32) {
                 for (int layer = 0; layer < n_hidden; ++layer) {
                     const bool last = (layer == n_hidden - 1);
@@ -792,52 +841,169 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                     }
                     v[0] = e[0] + e[2]; v[1] = e[1] + e[3];
                 }
-                // -- J_ji = sum_k R_j[k] g2[k] U_i[k]: this lane's 8 units, then the 4 lanes (g) of the query
-                // (element pairs: the compiler emits v_pk_mul_f32 / v_pk_fma_f32 for the 2-vectors)
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                f32x2 ja2 = {0.f, 0.f}, jb2 = ja2, jc2 = ja2, jd2 = ja2;  // J00, J11, J01, J10
+                mim_finish(R0, R1, g2, U0, U1);
+            } else if (MIMS) {
+                // ---- spherical 26-32-32-32-32-2 nets: J = [Wout D4 W4] D3 [W3 D2 W2 D1 W1 E] -----------------------------
+                // E = d(theta, sin phi, cos phi)/d(theta, phi) depends on the state, so the input side is not foldable into the
+                // weights: the two tangents go through hidden layers 1 and 2 in forward mode as before (zt3_i = W3 (g2 . W2 (g1 .
+                // zt1_i)) = U_i, fp32 accumulators).  The output side is folded (R_j = G_j g4, G_j = W4^T diag(Wout[j, :])) and
+                // J_ji = sum_k R_j[k] g3[k] U_i[k].  Per step 9 vectors are split instead of 12 and 56 fp16 MFMAs issue instead
+                // of 60.  Fragments: asynchronous LDS reads one phase ahead, as in the disk block above.
+                constexpr bool SPLIT = (PREC == BSDFD_PREC_SPLIT3);
+                constexpr int FR = 64 * 16;
+                constexpr int O_WH = NM * 64 * 4 + NM * PE_SLABS * 64 * 4;          // L.wh: W2, W3, W4 (2 fragments each)
+                constexpr int O_WHL = O_WH + (NH - 1) * NM * FR;                    // L.wh_lo
+                constexpr int O_WO = SPLIT ? O_WHL + (NH - 1) * NM * FR : O_WHL;    // L.wo
+                constexpr int O_WG = O_WO + FR;                                     // L.wg
+                constexpr int O_WGL = O_WG + 2 * NM * FR;                           // L.wg_lo
+                const unsigned lb = (unsigned)(uintptr_t)smem + (unsigned)lane * 16u;
+                float hv[NM][4], gv[NM][4], t0v[NM][4], t1v[NM][4];
+                Frag bh, bl, b0h, b0l, b1h, b1l;
+                f16x8 wAh[NM], wAl[NM], wBh[NM], wBl[NM];  // (W2 / W4 and W3: each set is requested behind the previous layer's MFMAs)
+                lds_read_b128_async_at<O_WH>(wAh[0], lb); lds_read_b128_async_at<O_WH + FR>(wAh[1], lb);
+                if (SPLIT) { lds_read_b128_async_at<O_WHL>(wAl[0], lb); lds_read_b128_async_at<O_WHL + FR>(wAl[1], lb); }
+                // -- hidden layer 1 (tangent pre-activations zt0 = W1 e_theta (constant), zt1 = W1 d(input)/d(phi))
 #pragma unroll
-                for (int m = 0; m < NM; ++m)
+                for (int m = 0; m < NM; ++m) {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const f32x2 gg2 = {g2[m][2 * h], g2[m][2 * h + 1]};
-                        const f32x2 r0 = {R0[m][2 * h], R0[m][2 * h + 1]}, r1 = {R1[m][2 * h], R1[m][2 * h + 1]};
-                        const f32x2 u0 = gg2 * (f32x2){U0[m][2 * h], U0[m][2 * h + 1]};
-                        const f32x2 u1 = gg2 * (f32x2){U1[m][2 * h], U1[m][2 * h + 1]};
-                        ja2 = __builtin_elementwise_fma(r0, u0, ja2);
-                        jc2 = __builtin_elementwise_fma(r0, u1, jc2);
-                        jd2 = __builtin_elementwise_fma(r1, u0, jd2);
-                        jb2 = __builtin_elementwise_fma(r1, u1, jb2);
+                    for (int r = 0; r < 4; ++r) {
+                        silu_grad_scaled(z[m][r], hv[m][r], gv[m][r]);
+                        t0v[m][r] = zt0[m][r] * gv[m][r];
+                        t1v[m][r] = zt1[m][r] * gv[m][r];
                     }
-                float ja = ja2[0] + ja2[1], jb = jb2[0] + jb2[1], jc = jc2[0] + jc2[1], jd = jd2[0] + jd2[1];
-                {
-                    // v_permlane32_swap(x, y): x[32..63] <-> y[0..31]; afterwards x + y holds, in the lower half-wave, x summed
-                    // over the lane pairs (l, l + 32) and, in the upper half, y summed over them.  v_permlane16_swap does the
-                    // same between the odd 16-lane rows of x and the even rows of y.  Two levels leave J00 | J01 | J11 | J10 in
-                    // rows 0 | 1 | 2 | 3 (row = g = lane >> 4), each summed over the query's 4 lanes.
-                    auto swap32 = [](float& x, float& y) {
-                        const auto t_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-                        x = __uint_as_float(t_[0]); y = __uint_as_float(t_[1]);
-                    };
-                    auto swap16 = [](float& x, float& y) {
-                        const auto t_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-                        x = __uint_as_float(t_[0]); y = __uint_as_float(t_[1]);
-                    };
-                    swap32(ja, jb);
-                    float sab = ja + jb;        // rows 0,1: J00 over (g, g+2) | rows 2,3: J11 over (g-2, g)
-                    swap32(jc, jd);
-                    float scd = jc + jd;        // rows 0,1: J01 | rows 2,3: J10
-                    swap16(sab, scd);
-                    const float tj = sab + scd; // row 0: J00, row 1: J01, row 2: J11, row 3: J10
-                    // w = 1 + c J on the diagonal rows (0, 2), c J on the others; det = w0 w2 - w1 w3 (mlp_brdf_sampling.py:44-46)
-                    float w = fmaf(cstep, tj, (g & 1) ? 0.0f : 1.0f), w2 = w;
-                    swap32(w, w2);              // w: rows (0,1,0,1) of the old w, w2: rows (2,3,2,3)
-                    float pr = w * w2, pr2 = pr;  // row 0: w0 w2, row 1: w1 w3
-                    swap16(pr, pr2);            // pr row 0 = old row 0, pr2 row 0 = old row 1
-                    const float det = pr - pr2; // valid in row 0 (g == 0), the lane that writes the query's results
-                    // forward: the reference divides (tmp_J /= J); v_rcp_f32 (1 ulp) * acc differs from the IEEE quotient by <= 2 ulp
-                    if (reverse) acc *= det; else acc *= __builtin_amdgcn_rcpf(det);
+                    split_pack<SPLIT>(hv[m], bh.p[2 * m], bh.p[2 * m + 1], bl.p[2 * m], bl.p[2 * m + 1]);
+                    split_pack<SPLIT>(t0v[m], b0h.p[2 * m], b0h.p[2 * m + 1], b0l.p[2 * m], b0l.p[2 * m + 1]);
+                    split_pack<SPLIT>(t1v[m], b1h.p[2 * m], b1h.p[2 * m + 1], b1l.p[2 * m], b1l.p[2 * m + 1]);
                 }
+                if (SPLIT) BSDFD_WAIT4(b1l.v, wAh[0], wAh[1], wAl[0], wAl[1]); else BSDFD_WAIT2(b1h.v, wAh[0], wAh[1]);
+                f32x4 U0[NM], U1[NM];
+#pragma unroll
+                for (int mo = 0; mo < NM; ++mo) {
+                    z[mo] = mfma16(wAh[mo], bh.v, zero4);
+                    U0[mo] = mfma16(wAh[mo], b0h.v, zero4);
+                    U1[mo] = mfma16(wAh[mo], b1h.v, zero4);
+                }
+                if (SPLIT) {
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) {
+                        z[mo] = mfma16(wAh[mo], bl.v, z[mo]);
+                        U0[mo] = mfma16(wAh[mo], b0l.v, U0[mo]);
+                        U1[mo] = mfma16(wAh[mo], b1l.v, U1[mo]);
+                    }
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) {
+                        z[mo] = mfma16(wAl[mo], bh.v, z[mo]);
+                        U0[mo] = mfma16(wAl[mo], b0h.v, U0[mo]);
+                        U1[mo] = mfma16(wAl[mo], b1h.v, U1[mo]);
+                    }
+                }
+                // next layer's fragments: requested behind this layer's MFMAs (so that the two sets are never live together),
+                // in flight during the next activation math (~170 VALU instructions: several LDS latencies)
+                lds_read_b128_async_at<O_WH + 2 * FR>(wBh[0], lb); lds_read_b128_async_at<O_WH + 3 * FR>(wBh[1], lb);
+                if (SPLIT) { lds_read_b128_async_at<O_WHL + 2 * FR>(wBl[0], lb); lds_read_b128_async_at<O_WHL + 3 * FR>(wBl[1], lb); }
+                // -- hidden layer 2
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        silu_grad_scaled(z[m][r], hv[m][r], gv[m][r]);
+                        t0v[m][r] = U0[m][r] * gv[m][r];
+                        t1v[m][r] = U1[m][r] * gv[m][r];
+                    }
+                    split_pack<SPLIT>(hv[m], bh.p[2 * m], bh.p[2 * m + 1], bl.p[2 * m], bl.p[2 * m + 1]);
+                    split_pack<SPLIT>(t0v[m], b0h.p[2 * m], b0h.p[2 * m + 1], b0l.p[2 * m], b0l.p[2 * m + 1]);
+                    split_pack<SPLIT>(t1v[m], b1h.p[2 * m], b1h.p[2 * m + 1], b1l.p[2 * m], b1l.p[2 * m + 1]);
+                }
+                if (SPLIT) BSDFD_WAIT4(b1l.v, wBh[0], wBh[1], wBl[0], wBl[1]); else BSDFD_WAIT2(b1h.v, wBh[0], wBh[1]);
+                // z3 first; U_i = zt3_i are needed only when J is formed
+#pragma unroll
+                for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(wBh[mo], bh.v, zero4);
+                if (SPLIT) {
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(wBh[mo], bl.v, z[mo]);
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(wBl[mo], bh.v, z[mo]);
+                }
+#pragma unroll
+                for (int mo = 0; mo < NM; ++mo) {
+                    U0[mo] = mfma16(wBh[mo], b0h.v, zero4);
+                    U1[mo] = mfma16(wBh[mo], b1h.v, zero4);
+                }
+                if (SPLIT) {
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) {
+                        U0[mo] = mfma16(wBh[mo], b0l.v, U0[mo]);
+                        U1[mo] = mfma16(wBh[mo], b1l.v, U1[mo]);
+                    }
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) {
+                        U0[mo] = mfma16(wBl[mo], b0h.v, U0[mo]);
+                        U1[mo] = mfma16(wBl[mo], b1h.v, U1[mo]);
+                    }
+                }
+                lds_read_b128_async_at<O_WH + 4 * FR>(wAh[0], lb); lds_read_b128_async_at<O_WH + 5 * FR>(wAh[1], lb);
+                if (SPLIT) { lds_read_b128_async_at<O_WHL + 4 * FR>(wAl[0], lb); lds_read_b128_async_at<O_WHL + 5 * FR>(wAl[1], lb); }
+                // -- hidden layer 3 (its silu' stays in fp32: the middle factor of J)
+                float g3[NM][4];
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) silu_grad_scaled(z[m][r], hv[m][r], g3[m][r]);
+                    split_pack<SPLIT>(hv[m], bh.p[2 * m], bh.p[2 * m + 1], bl.p[2 * m], bl.p[2 * m + 1]);
+                }
+                if (SPLIT) BSDFD_WAIT4(bl.v, wAh[0], wAh[1], wAl[0], wAl[1]); else BSDFD_WAIT2(bh.v, wAh[0], wAh[1]);
+#pragma unroll
+                for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(wAh[mo], bh.v, zero4);
+                if (SPLIT) {
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(wAh[mo], bl.v, z[mo]);
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(wAl[mo], bh.v, z[mo]);
+                }
+                f16x8 wo, g0h[NM], g1h[NM], g0l[NM], g1l[NM];
+                lds_read_b128_async_at<O_WO>(wo, lb);
+                lds_read_b128_async_at<O_WG>(g0h[0], lb); lds_read_b128_async_at<O_WG + FR>(g0h[1], lb);
+                lds_read_b128_async_at<O_WG + 2 * FR>(g1h[0], lb); lds_read_b128_async_at<O_WG + 3 * FR>(g1h[1], lb);
+                // -- hidden layer 4 -> v, R0, R1
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) silu_grad_scaled(z[m][r], hv[m][r], gv[m][r]);
+                    split_pack<SPLIT>(hv[m], bh.p[2 * m], bh.p[2 * m + 1], bl.p[2 * m], bl.p[2 * m + 1]);
+                    split_pack<SPLIT>(gv[m], b0h.p[2 * m], b0h.p[2 * m + 1], b0l.p[2 * m], b0l.p[2 * m + 1]);
+                }
+                BSDFD_WAIT5(b0h.v, wo, g0h[0], g0h[1], g1h[0], g1h[1]);
+                // (the lo parts of G are requested only now — they feed the last 4 of the 14 MFMAs below, ~150 cycles away —
+                //  so that they are not live during the activation math: with them the kernel spilled 2 VGPRs)
+                if (SPLIT) {
+                    lds_read_b128_async_at<O_WGL>(g0l[0], lb); lds_read_b128_async_at<O_WGL + FR>(g0l[1], lb);
+                    lds_read_b128_async_at<O_WGL + 2 * FR>(g1l[0], lb); lds_read_b128_async_at<O_WGL + 3 * FR>(g1l[1], lb);
+                }
+                f32x4 R0[NM], R1[NM];
+                {
+                    f32x4 e = mfma16(wo, bh.v, zero4);
+#pragma unroll
+                    for (int mo = 0; mo < NM; ++mo) {
+                        R0[mo] = mfma16(g0h[mo], b0h.v, zero4);
+                        R1[mo] = mfma16(g1h[mo], b0h.v, zero4);
+                    }
+                    if (SPLIT) {
+                        e = mfma16(wo, bl.v, e);
+#pragma unroll
+                        for (int mo = 0; mo < NM; ++mo) {
+                            R0[mo] = mfma16(g0h[mo], b0l.v, R0[mo]);
+                            R1[mo] = mfma16(g1h[mo], b0l.v, R1[mo]);
+                        }
+                        BSDFD_WAIT4(R1[1], g0l[0], g0l[1], g1l[0], g1l[1]);
+#pragma unroll
+                        for (int mo = 0; mo < NM; ++mo) {
+                            R0[mo] = mfma16(g0l[mo], b0h.v, R0[mo]);
+                            R1[mo] = mfma16(g1l[mo], b0h.v, R1[mo]);
+                        }
+                    }
+                    v[0] = e[0] + e[2]; v[1] = e[1] + e[3];
+                }
+                mim_finish(R0, R1, g3, U0, U1);
             } else {
                 // ---- fp16 MFMA path ----
                 // Per layer: one sigmoid per unit -> (hs, g); tangents scaled by g; the lane's own 8
@@ -970,7 +1136,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
             }
 
             // det(I + c*J) with the row convention of mlp_brdf_sampling.py:44-46; signed.
-            if (JAC && !MIM) {
+            if (JAC && !MIM && !MIMS) {
                 const float j00 = 1.0f + cstep * d0[0];
                 const float j01 = cstep * d1[0];
                 const float j10 = cstep * d0[1];
@@ -1116,9 +1282,11 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
     // folded layer-1 tangent matrices W2 diag(W1[:, i]), i = 0, 1, of the disk nets (FOLD_L1 in the kernel)
     const bool fold = d.domain == BSDFD_DOMAIN_DISK && prec != BSDFD_PREC_F32 && NH >= 2 && NM == 2;
     const int NFOLD = 2;
-    // ... and, for the 3-hidden-layer disk nets, the output side folded the same way (MIM in the kernel):
-    // G_j = W3^T diag(Wout[j, :]), j = 0, 1, so that (Wout D3 W3)^T[:, j] = G_j g3
-    const bool mim = fold && NH == 3;
+    // ... and the output side folded the same way (MIM in the kernel), with W_L the last hidden-to-hidden matrix:
+    // G_j = W_L^T diag(Wout[j, :]), j = 0, 1, so that (Wout D_L W_L)^T[:, j] = G_j g_L
+    // (disk 25-32x3-2 and spherical 26-32x4-2: the two nets the reference's plugins load)
+    const bool mim = prec != BSDFD_PREC_F32 && NM == 2 &&
+                     ((d.domain == BSDFD_DOMAIN_DISK && NH == 3) || (d.domain == BSDFD_DOMAIN_SPHERICAL && NH == 4));
     if (fold) {
         L.wf = off; off += NFOLD * NM * KC * 64 * 16;
         L.wf_lo = off;
@@ -1128,11 +1296,12 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
         L.wg = off; off += NFOLD * NM * KC * 64 * 16;
         L.wg_lo = off;
         if (prec == BSDFD_PREC_SPLIT3) off += NFOLD * NM * KC * 64 * 16;
-        // the MIM kernel addresses its fragments with compile-time offsets: keep the two in step
+        // the MIM kernels address their fragments with compile-time offsets: keep the two in step
         const int fr = 64 * 16, o_wh = NM * 64 * 4 + NM * PE_SLABS * 64 * 4, o_whl = o_wh + (NH - 1) * NM * fr;
         const bool sp = prec == BSDFD_PREC_SPLIT3;
-        const int o_wo = sp ? o_whl + (NH - 1) * NM * fr : o_whl, o_wf = o_wo + fr, o_wfl = o_wf + 2 * NM * fr;
-        const int o_wg = sp ? o_wfl + 2 * NM * fr : o_wfl, o_wgl = o_wg + 2 * NM * fr;
+        const int o_wo = sp ? o_whl + (NH - 1) * NM * fr : o_whl;
+        const int o_wf = fold ? o_wo + fr : 0, o_wfl = fold ? o_wf + 2 * NM * fr : 0;
+        const int o_wg = fold ? (sp ? o_wfl + 2 * NM * fr : o_wfl) : o_wo + fr, o_wgl = o_wg + 2 * NM * fr;
         if (L.wh != o_wh || L.wh_lo != (sp ? o_whl : o_wh) || L.wo != o_wo || L.wf != o_wf || L.wf_lo != o_wfl || L.wg != o_wg ||
             L.wg_lo != o_wgl) {
             std::fprintf(stderr, "bsdfd: weight-image layout drifted from the kernel's compile-time offsets\n");
@@ -1217,10 +1386,10 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
                     for (int kc = 0; kc < KC; ++kc)
                         for (int l = 0; l < 64; ++l)
                             for (int j = 0; j < 8; ++j) {
-                                const int k = 16 * (2 * kc + (j >> 2)) + 4 * (l >> 4) + (j & 3);  // layer-3 unit (contraction index)
-                                const int unit = 16 * mo + (l & 15);                                // layer-2 unit (row of G_i)
-                                // G_i[unit][k] = W3[k][unit] * Wout[i][k], Wout already scaled by -ln 2 (d.w_out)
-                                const double v = (double)d.w_hidden[((size_t)1 * W + k) * W + unit] * (double)d.w_out[(size_t)i * W + k];
+                                const int k = 16 * (2 * kc + (j >> 2)) + 4 * (l >> 4) + (j & 3);  // unit of the LAST hidden layer (contraction index)
+                                const int unit = 16 * mo + (l & 15);                                // unit of the layer before it (row of G_i)
+                                // G_i[unit][k] = W_L[k][unit] * Wout[i][k], Wout already scaled by -ln 2 (d.w_out)
+                                const double v = (double)d.w_hidden[((size_t)(NH - 2) * W + k) * W + unit] * (double)d.w_out[(size_t)i * W + k];
                                 const size_t idx = ((((size_t)i * NM + mo) * KC + kc) * 64 + l) * 8 + j;
                                 const float hi = f16_round((float)v);
                                 H(L.wg)[idx] = f32_to_f16_bits((float)v);
