@@ -1302,7 +1302,7 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
         const int o_wo = sp ? o_whl + (NH - 1) * NM * fr : o_whl;
         const int o_wf = fold ? o_wo + fr : 0, o_wfl = fold ? o_wf + 2 * NM * fr : 0;
         const int o_wg = fold ? (sp ? o_wfl + 2 * NM * fr : o_wfl) : o_wo + fr, o_wgl = o_wg + 2 * NM * fr;
-        if (L.wh != o_wh || L.wh_lo != (sp ? o_whl : o_wh) || L.wo != o_wo || L.wf != o_wf || L.wf_lo != o_wfl || L.wg != o_wg ||
+        if (L.wh != o_wh || L.wh_lo != o_whl || L.wo != o_wo || L.wf != o_wf || L.wf_lo != o_wfl || L.wg != o_wg ||
             L.wg_lo != o_wgl) {
             std::fprintf(stderr, "bsdfd: weight-image layout drifted from the kernel's compile-time offsets\n");
             std::abort();

@@ -15,7 +15,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-from conftest import load_case  # noqa: E402
+from conftest import same_density,  load_case  # noqa: E402
 from oracle import bsdf_oracle as O  # noqa: E402
 
 
@@ -125,8 +125,10 @@ def test_mixed_material_table_matches_per_material_calls():
     # sample(wi) + pdf(wi, wl) of the same intersections in one launch per kernel signature
     wl = _wi("disk", n, 9)
     wo_f, po_f, pl_f = tab.sample_pdf(ids, wi, wl, seed=11, offset=5)
-    assert torch.allclose(wo_f, a[0], atol=2e-6, rtol=0) and torch.allclose(po_f, a[1], rtol=2e-5, atol=0)
-    assert torch.allclose(pl_f, tab.pdf(ids, wi, wl), rtol=2e-5, atol=0)
+    # (the fused kernel carries the Jacobian in forward mode, the single-op kernels form it by meeting in the middle: the same
+    #  numbers up to fp32 noise, conftest.same_density)
+    assert torch.allclose(wo_f, a[0], atol=2e-6, rtol=0) and same_density(po_f, a[1])
+    assert same_density(pl_f, tab.pdf(ids, wi, wl))
     # a bucketing plan computed once serves both calls
     plan = tab.bucket(ids)
     c = tab.sample(plan, wi, seed=11, offset=5)

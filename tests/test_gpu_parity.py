@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
-from conftest import GOLDEN_CASES, load_case  # noqa: E402
+from conftest import GOLDEN_CASES, load_case, same_density  # noqa: E402
 from oracle import bsdf_oracle as O  # noqa: E402
 
 
@@ -502,7 +502,7 @@ def test_fused_sample_pdf_equals_the_two_calls(stem, variant):
         pl = s.plugin_pdf(wi, wl, T=T, variant=variant)
         wo2, p2, pl2 = s.plugin_sample_pdf(wi, wl, x0, T=T, variant=variant, seed=3, offset=11)
         assert torch.allclose(wo, wo2, rtol=0, atol=2e-6)
-        assert torch.allclose(p, p2, rtol=2e-5, atol=0) and torch.allclose(pl, pl2, rtol=2e-5, atol=0)
+        assert same_density(p2, p) and same_density(pl2, pl)   # (forward-mode Jacobian vs meet-in-the-middle: fp32 noise)
     with pytest.raises(RuntimeError, match="sample_pdf|null|wl"):
         from bsdf_diffusion_sampling_amd import _lib
         import ctypes as C
@@ -519,8 +519,8 @@ def test_plugin_core_sample_pdf_t():
     wl = wi.flip(0).contiguous()
     wo, po, pl = plug.sample_pdf_t(wi, wl, seed=7)
     wo2, po2 = plug.sample_t(wi, seed=7)
-    assert torch.allclose(wo, wo2, atol=2e-6, rtol=0) and torch.allclose(po, po2, rtol=2e-5, atol=0)
-    assert torch.allclose(pl, plug.pdf_t(wi, wl), rtol=2e-5, atol=0)
+    assert torch.allclose(wo, wo2, atol=2e-6, rtol=0) and same_density(po, po2)
+    assert same_density(pl, plug.pdf_t(wi, wl))
 
 
 @pytest.mark.parametrize("stem,variant", [("chm_orange_rgb_disk", 0), ("aniso_miro_7_rgb_disk", 0), ("aniso_miro_7_rgb_spherical", 0),

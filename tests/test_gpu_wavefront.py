@@ -76,10 +76,11 @@ def test_shade_matches_oracle(plugin):
     assert np.isfinite(got).all()
     err = np.abs(got - want) / (np.abs(want) + 1e-3)
     assert np.percentile(err, 99.9) < 2e-4 and err.max() < 5e-3, (np.percentile(err, 99.9), err.max())
-    # the sampler call inside the pass is the plugin's own pair: pdf_l == plugin.pdf_t(wi, wl) (the fused
-    # launch is a different kernel instantiation: FMA contraction may differ in the last bits)
+    # the sampler call inside the pass is the plugin's own pair: pdf_l == plugin.pdf_t(wi, wl) up to fp32 noise (the fused
+    # launch carries the Jacobian in forward mode, the single-op kernel forms it by meeting in the middle)
+    from conftest import same_density
     pl = r.plugin.pdf_t(torch.from_numpy(b["wi"]).to(r.device), torch.from_numpy(b["wl"]).to(r.device))
-    assert torch.allclose(pl.cpu(), torch.from_numpy(b["pdf_l"]), rtol=2e-5, atol=0)
+    assert same_density(pl, b["pdf_l"])
 
 
 def test_row_split_invariance_and_pass_streams():
