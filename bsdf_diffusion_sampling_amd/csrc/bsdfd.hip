@@ -23,6 +23,11 @@
 //     steps: it is computed once per query and used as the C-in accumulator of the
 //     per-step layer-1 MFMA.
 //   * weights live in LDS as ready-made MFMA A-fragments (one ds_read_b128 per use).
+//   * the 2x2 Jacobian of the reference's two nets (disk 32x3, spherical 32x4) is formed by MEETING IN THE MIDDLE: the host
+//     also packs the output-side folded matrices G_j = W_L^T diag(Wout[j, :]); per step two tangent layers' worth of hi/lo
+//     splits, scalings and MFMAs are replaced by one fp32 2x2 bilinear form and a 5-swap cross-lane reduction (blocks
+//     "MIM" / "MIMS" in the Euler step; other depths / widths and the fused sample+pdf kernel run forward-mode tangents).
+//   * a sample launch can write, and a pdf launch read, the per-query context (what depends on wi alone): bsdfd_opts.
 //   * precision of the contractions: exact fp32 MFMA (16x16x4), or fp16 MFMA (16x16x32)
 //     with hi+lo operand splitting (3 products, fp32 accumulate), or plain fp16.
 #include <hip/hip_runtime.h>
@@ -1917,6 +1922,6 @@ float bsdfd_last_kernel_ms(bsdfd_handle h) {
 }
 
 const char* bsdfd_last_error(void) { return g_err.c_str(); }
-const char* bsdfd_version(void) { return "bsdfd 0.2 (gfx950)"; }
+const char* bsdfd_version(void) { return "bsdfd 0.3 (gfx950)"; }
 
 }  // extern "C"
