@@ -325,14 +325,14 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
     // (three folded matrices, d/dphi = cos(phi) F_sin g - sin(phi) F_cos g: +6 fp16 MFMAs, -2 fp32 MFMAs, one split less)
     // was built and measured at +-0.2 %: not kept.
     constexpr bool FOLD_L1 = JAC && NM == 2 && PREC != BSDFD_PREC_F32 && DOMAIN == BSDFD_DOMAIN_DISK && NH == 3;
-    // MIM (same nets, single-op kernels): the OUTPUT side of the Jacobian is folded as well and the two halves meet in
-    // the middle — see the block in the Euler step.  The fused sample+pdf instantiation keeps the forward-mode tangents
-    // (its two-phase state leaves no room for the asynchronously fetched fragments: 9 spilled VGPRs when tried).
-    // History: with only the input side folded and every fragment register-resident the kernel wanted 4 VGPRs more than 3
-    // waves/SIMD allow; round 2 shipped a "PIN" arrangement (resident hi parts, the 4 folded lo fragments fetched
-    // asynchronously per step: -3.7 %); MIM supersedes it (-5.7 % on top, profiles/r03_ab/mim_*.txt).
-    constexpr bool MIM = FOLD_L1 && KC == 1 && !FUSED;
-    // the spherical 26-32x4-2 nets: two regular tangent layers, then the same meeting in the middle (block "MIMS" below)
+    // MIM (same nets): the OUTPUT side of the Jacobian is folded as well and the two halves meet in the middle — see the
+    // block in the Euler step.  History: with only the input side folded and every fragment register-resident the kernel
+    // wanted 4 VGPRs more than 3 waves/SIMD allow; round 2 shipped a "PIN" arrangement (resident hi parts, the 4 folded lo
+    // fragments fetched asynchronously per step: -3.7 %); MIM supersedes it (-5.7 % on top, profiles/r03_ab/).
+    constexpr bool MIM = FOLD_L1 && KC == 1;
+    // the spherical 26-32x4-2 nets: two regular tangent layers, then the same meeting in the middle (block "MIMS" below);
+    // not in the fused sample+pdf instantiation, whose two-phase state leaves no room for the asynchronously fetched
+    // fragments (15 spilled VGPRs when tried — unsafe next to asynchronous destinations): it keeps forward-mode tangents
     constexpr bool MIMS = JAC && NM == 2 && PREC != BSDFD_PREC_F32 && DOMAIN == BSDFD_DOMAIN_SPHERICAL && NH == 4 && !FUSED;
     const int n_hidden = NH ? NH : p.n_hidden;
     const int lane = threadIdx.x & 63;
@@ -723,8 +723,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                 constexpr bool SPLIT = (PREC == BSDFD_PREC_SPLIT3);
                 // Weight fragments: 25 per step (W2, W3 hi/lo, Wout, F_0, F_1, G_0, G_1 hi/lo).  They do not fit the register
                 // budget of 3 waves/SIMD next to the flow state, so each layer's fragments are requested from LDS with
-                // asynchronous reads one phase ahead (while the previous layer's MFMAs / this layer's activation math run)
-                // and waited for once, right before the layer's first MFMA.  The image layout of this instantiation is a
+                // asynchronous reads one phase ahead (behind the previous layer's MFMAs, in flight during this layer's activation
+                // math; the lo parts, which feed a layer's last MFMAs, behind the wait for its hi parts) and waited for once.  The image layout of this instantiation is a
                 // compile-time constant (build_image checks it), so every read is `lane base + immediate offset`.
                 constexpr int FR = 64 * 16;                                         // bytes of one fragment
                 constexpr int O_WH = NM * 64 * 4 + NM * PE_SLABS * 64 * 4;          // L.wh
@@ -737,16 +737,37 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                 const unsigned lb = (unsigned)(uintptr_t)smem + (unsigned)lane * 16u;
                 float hv[NM][4], gv[NM][4];
                 Frag bh, bl, gh, gl;
-                // -- hidden layer 1 -> z2, U0, U1
-                f16x8 w2h[NM], w2l[NM], f0h[NM], f1h[NM], f0l[NM], f1l[NM];
-                lds_read_b128_async_at<O_WH>(w2h[0], lb); lds_read_b128_async_at<O_WH + FR>(w2h[1], lb);
-                lds_read_b128_async_at<O_WF>(f0h[0], lb); lds_read_b128_async_at<O_WF + FR>(f0h[1], lb);
-                lds_read_b128_async_at<O_WF + 2 * FR>(f1h[0], lb); lds_read_b128_async_at<O_WF + 3 * FR>(f1h[1], lb);
-                if (SPLIT) {
+                // Request points.  EARLY (single-op kernels): a layer's fragments are requested before the previous layer's MFMAs
+                // and its lo parts together with the hi parts — measured 1 % faster than LATE.  LATE (fused sample+pdf kernel,
+                // whose second phase keeps more state live): behind the previous layer's MFMAs, and the lo parts — which feed a
+                // layer's last MFMAs — only behind the wait for its hi parts; this keeps the two-phase kernel free of spills.
+                constexpr bool LATE = FUSED;
+                f16x8 w2h[NM], w2l[NM], f0h[NM], f1h[NM], f0l[NM], f1l[NM], w3h[NM], w3l[NM], wo, g0h[NM], g1h[NM], g0l[NM], g1l[NM];
+                auto req_A_lo = [&] {
+                    if (!SPLIT) return;
                     lds_read_b128_async_at<O_WHL>(w2l[0], lb); lds_read_b128_async_at<O_WHL + FR>(w2l[1], lb);
                     lds_read_b128_async_at<O_WFL>(f0l[0], lb); lds_read_b128_async_at<O_WFL + FR>(f0l[1], lb);
                     lds_read_b128_async_at<O_WFL + 2 * FR>(f1l[0], lb); lds_read_b128_async_at<O_WFL + 3 * FR>(f1l[1], lb);
-                }
+                };
+                auto req_B = [&] {
+                    lds_read_b128_async_at<O_WH + 2 * FR>(w3h[0], lb); lds_read_b128_async_at<O_WH + 3 * FR>(w3h[1], lb);
+                    if (SPLIT) { lds_read_b128_async_at<O_WHL + 2 * FR>(w3l[0], lb); lds_read_b128_async_at<O_WHL + 3 * FR>(w3l[1], lb); }
+                };
+                auto req_C_hi = [&] {
+                    lds_read_b128_async_at<O_WO>(wo, lb);
+                    lds_read_b128_async_at<O_WG>(g0h[0], lb); lds_read_b128_async_at<O_WG + FR>(g0h[1], lb);
+                    lds_read_b128_async_at<O_WG + 2 * FR>(g1h[0], lb); lds_read_b128_async_at<O_WG + 3 * FR>(g1h[1], lb);
+                };
+                auto req_C_lo = [&] {
+                    if (!SPLIT) return;
+                    lds_read_b128_async_at<O_WGL>(g0l[0], lb); lds_read_b128_async_at<O_WGL + FR>(g0l[1], lb);
+                    lds_read_b128_async_at<O_WGL + 2 * FR>(g1l[0], lb); lds_read_b128_async_at<O_WGL + 3 * FR>(g1l[1], lb);
+                };
+                // -- hidden layer 1 -> z2, U0, U1
+                lds_read_b128_async_at<O_WH>(w2h[0], lb); lds_read_b128_async_at<O_WH + FR>(w2h[1], lb);
+                lds_read_b128_async_at<O_WF>(f0h[0], lb); lds_read_b128_async_at<O_WF + FR>(f0h[1], lb);
+                lds_read_b128_async_at<O_WF + 2 * FR>(f1h[0], lb); lds_read_b128_async_at<O_WF + 3 * FR>(f1h[1], lb);
+                if (!LATE) req_A_lo();
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
 #pragma unroll
@@ -755,11 +776,11 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                     split_pack<SPLIT>(gv[m], gh.p[2 * m], gh.p[2 * m + 1], gl.p[2 * m], gl.p[2 * m + 1]);
                 }
                 BSDFD_WAIT6(gh.v, w2h[0], w2h[1], f0h[0], f0h[1], f1h[0], f1h[1]);
-                if (SPLIT) BSDFD_WAIT6(gl.v, w2l[0], w2l[1], f0l[0], f0l[1], f1l[0], f1l[1]);
-                // next layer's fragments: in flight during this layer's MFMAs and the next activation math
-                f16x8 w3h[NM], w3l[NM];
-                lds_read_b128_async_at<O_WH + 2 * FR>(w3h[0], lb); lds_read_b128_async_at<O_WH + 3 * FR>(w3h[1], lb);
-                if (SPLIT) { lds_read_b128_async_at<O_WHL + 2 * FR>(w3l[0], lb); lds_read_b128_async_at<O_WHL + 3 * FR>(w3l[1], lb); }
+                if (LATE) req_A_lo();
+                else {
+                    if (SPLIT) BSDFD_WAIT6(gl.v, w2l[0], w2l[1], f0l[0], f0l[1], f1l[0], f1l[1]);
+                    req_B();
+                }
                 // z2 first (the next activation needs nothing else); the 12 MFMAs of U0, U1 are off the critical path — J is
                 // formed at the end of the step — so they run in the matrix pipe under the next layer's activation math
                 f32x4 U0[NM], U1[NM];
@@ -768,8 +789,10 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                 if (SPLIT) {
 #pragma unroll
                     for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(w2h[mo], bl.v, z[mo]);
+                    if (!LATE) {
 #pragma unroll
-                    for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(w2l[mo], bh.v, z[mo]);
+                        for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(w2l[mo], bh.v, z[mo]);
+                    }
                 }
 #pragma unroll
                 for (int mo = 0; mo < NM; ++mo) {
@@ -782,12 +805,18 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                         U0[mo] = mfma16(f0h[mo], gl.v, U0[mo]);
                         U1[mo] = mfma16(f1h[mo], gl.v, U1[mo]);
                     }
+                    if (LATE) {
+                        BSDFD_WAIT6(U1[1], w2l[0], w2l[1], f0l[0], f0l[1], f1l[0], f1l[1]);
+#pragma unroll
+                        for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(w2l[mo], bh.v, z[mo]);
+                    }
 #pragma unroll
                     for (int mo = 0; mo < NM; ++mo) {
                         U0[mo] = mfma16(f0l[mo], gh.v, U0[mo]);
                         U1[mo] = mfma16(f1l[mo], gh.v, U1[mo]);
                     }
                 }
+                if (LATE) req_B();
                 // -- hidden layer 2 -> z3 (its silu' stays in fp32: the middle factor of J)
                 float g2[NM][4];
 #pragma unroll
@@ -797,14 +826,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                     split_pack<SPLIT>(hv[m], bh.p[2 * m], bh.p[2 * m + 1], bl.p[2 * m], bl.p[2 * m + 1]);
                 }
                 if (SPLIT) BSDFD_WAIT4(bl.v, w3h[0], w3h[1], w3l[0], w3l[1]); else BSDFD_WAIT2(bh.v, w3h[0], w3h[1]);
-                f16x8 wo, g0h[NM], g1h[NM], g0l[NM], g1l[NM];
-                lds_read_b128_async_at<O_WO>(wo, lb);
-                lds_read_b128_async_at<O_WG>(g0h[0], lb); lds_read_b128_async_at<O_WG + FR>(g0h[1], lb);
-                lds_read_b128_async_at<O_WG + 2 * FR>(g1h[0], lb); lds_read_b128_async_at<O_WG + 3 * FR>(g1h[1], lb);
-                if (SPLIT) {
-                    lds_read_b128_async_at<O_WGL>(g0l[0], lb); lds_read_b128_async_at<O_WGL + FR>(g0l[1], lb);
-                    lds_read_b128_async_at<O_WGL + 2 * FR>(g1l[0], lb); lds_read_b128_async_at<O_WGL + 3 * FR>(g1l[1], lb);
-                }
+                if (!LATE) { req_C_hi(); req_C_lo(); }
 #pragma unroll
                 for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(w3h[mo], bh.v, zero4);
                 if (SPLIT) {
@@ -813,6 +835,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
 #pragma unroll
                     for (int mo = 0; mo < NM; ++mo) z[mo] = mfma16(w3l[mo], bh.v, z[mo]);
                 }
+                if (LATE) req_C_hi();
                 // -- hidden layer 3 -> v, R0, R1
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
@@ -822,7 +845,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                     split_pack<SPLIT>(gv[m], gh.p[2 * m], gh.p[2 * m + 1], gl.p[2 * m], gl.p[2 * m + 1]);
                 }
                 BSDFD_WAIT5(gh.v, wo, g0h[0], g0h[1], g1h[0], g1h[1]);
-                if (SPLIT) BSDFD_WAIT4(gl.v, g0l[0], g0l[1], g1l[0], g1l[1]);
+                if (LATE) req_C_lo();  // (the lo parts feed the last 4 of the 14 MFMAs below)
+                else if (SPLIT) BSDFD_WAIT4(gl.v, g0l[0], g0l[1], g1l[0], g1l[1]);
                 f32x4 R0[NM], R1[NM];
                 {
                     f32x4 e = mfma16(wo, bh.v, zero4);
@@ -838,6 +862,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_ker
                             R0[mo] = mfma16(g0h[mo], gl.v, R0[mo]);
                             R1[mo] = mfma16(g1h[mo], gl.v, R1[mo]);
                         }
+                        if (LATE) BSDFD_WAIT4(R1[1], g0l[0], g0l[1], g1l[0], g1l[1]);
 #pragma unroll
                         for (int mo = 0; mo < NM; ++mo) {
                             R0[mo] = mfma16(g0l[mo], gh.v, R0[mo]);

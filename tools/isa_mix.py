@@ -184,6 +184,7 @@ def main():
                             os.path.join(root, "bsdf_diffusion_sampling_amd", "csrc", "bsdfd.hip"), "-o", asm], check=True)
             rc = 0
             for key in ("flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E", "flow_kernelILi0ELi2ELi3ELb1ELi3ELb0E",    # disk 32x3: split3, f16
+                        "flow_kernelILi0ELi2ELi2ELb1ELi3ELb1E", "flow_kernelILi0ELi2ELi3ELb1ELi3ELb1E",    # ... fused sample+pdf
                         "flow_kernelILi1ELi2ELi2ELb1ELi4ELb0E", "flow_kernelILi1ELi2ELi3ELb1ELi4ELb0E"):   # spherical 32x4
                 n, bad = check_async(asm, key)
                 print(f"{key}: {n} asynchronous ds_read_b128, {len(bad)} violations")
