@@ -677,3 +677,35 @@ def test_plugin_level_vs_reference_plugin_goldens(stem):
     if not full:
         got = s.plugin_pdf(_t(p["pdf_wi3"]), _t(p["pdf_wo3"]), T=T, variant=variant).cpu().numpy()
         assert np.all(got[:16] == 0)  # cos(theta_o) <= 0 and cos(theta_i) <= 0 lanes
+
+
+@pytest.mark.parametrize("stem,variant", [("chm_orange_rgb_disk", 0), ("aniso_miro_7_rgb_spherical", 0)])
+def test_fused_sample_pdf_in_f16_precision(stem, variant):
+    """The fused sample+pdf kernels also exist in the single-pass fp16 mode (tcnn class, 1e-2): same directions and
+    densities as the two single-op calls of that mode, and close to the split3 results."""
+    g, fw = load_case(stem)
+    s16, s3 = _sampler(fw, "f16"), _sampler(fw, "split3")
+    rng = np.random.default_rng(5)
+    n = 20000
+    def dirs(lo):
+        z, ph = rng.uniform(lo, 1.0, size=n), rng.uniform(0, 2 * np.pi, size=n)
+        r = np.sqrt(1 - z * z)
+        return _t(np.stack([r * np.cos(ph), r * np.sin(ph), z], 1))
+    wi, wl = dirs(0.05), dirs(0.02)
+    x0 = _t(np.tile(g["x0"], (n // 2048 + 1, 1))[:n])
+    T = 4 if fw.domain == 0 else 8
+    wo, p = s16.plugin_sample(wi, x0, T=T, variant=variant)
+    pl = s16.plugin_pdf(wi, wl, T=T, variant=variant)
+    wo2, p2, pl2 = s16.plugin_sample_pdf(wi, wl, x0, T=T, variant=variant)
+    assert torch.allclose(wo, wo2, atol=2e-3, rtol=0)
+    # plain-fp16 contractions carry 2^-11 operand error, which the flow amplifies into 3e-3 .. 9e-2 on the density (DESIGN §4):
+    # two evaluation orders of that mode (forward-mode tangents in the spherical fused kernel, meet-in-the-middle elsewhere)
+    # agree at that level, not at fp32 noise
+    for a_, b_ in ((p2, p), (pl2, pl)):
+        a_, b_ = a_.cpu().numpy().astype(np.float64), b_.cpu().numpy().astype(np.float64)
+        ok = np.abs(b_) > 1e-6 * np.percentile(np.abs(b_), 99)
+        rel = np.abs(a_ - b_)[ok] / np.abs(b_[ok])
+        assert np.isfinite(a_).all() and np.median(rel) < 2e-2 and np.percentile(rel, 99) < 0.5, (np.median(rel), np.percentile(rel, 99))
+    wo3, _ = s3.plugin_sample(wi, x0, T=T, variant=variant)
+    # (a row within fp16 noise of the r^2 >= 0.995 / cos guards may flip to the guarded value in one precision only)
+    assert ((wo2 - wo3).abs().max(dim=1).values > 2e-2).float().mean().item() < 2e-3
