@@ -292,8 +292,17 @@ __device__ __forceinline__ float von_mises_sample(float mu, float kappa, unsigne
 //            measured -3..4 % per Euler step), 0 = run-time p.n_hidden (any depth).
 //   FUSED  : compiled with the two-phase OP_SAMPLE_PDF loop (its own instantiation: the loop costs the
 //            single-op kernels 2-4 % when compiled into them)
+// Waves per SIMD the register allocator is asked to make room for: 3 for the 32-wide nets (<= 168 VGPRs), 2 for the 64-wide.
+// The one exception is the disk 32x3 split3 single-op kernel (the headline workload): asked for 2, the scheduler stops
+// trading instruction-level parallelism for registers and still lands at 165 VGPRs = 3 waves/SIMD, 1.1 % faster than the
+// 156-VGPR schedule it produces when asked for 3 (profiles/r03_ab/ab13).  tools/isa_mix.py --check-async (a CPU test) fails
+// if a toolchain ever takes that kernel past 168 VGPRs, i.e. down to 2 waves/SIMD (which measured 4 % slower on the
+// spherical kernel).
+// (written without commas: __launch_bounds__ is a variadic macro)
+#define BSDFD_MIN_WAVES \
+    (NM != 2 ? 2 : ((DOMAIN == BSDFD_DOMAIN_DISK && PREC == BSDFD_PREC_SPLIT3 && JAC && NH == 3 && !FUSED) ? 2 : 3))
 template <int DOMAIN, int NM, int PREC, bool JAC, int NH, bool FUSED>
-__global__ __launch_bounds__(NM == 2 ? 256 : 512, NM == 2 ? 3 : 2) void flow_kernel(const KParams p) {
+__global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // this workgroup's share of the work: the whole batch, or one material's bucket
     const char* img = p.img;

@@ -163,9 +163,14 @@ def check_async(path, key):
                 m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", l2)
                 if m:
                     meta["scratch"] = int(m.group(1))
+                m = re.search(r"\.vgpr_count:\s+(\d+)", l2)
+                if m:
+                    meta["vgprs"] = int(m.group(1))
             break
     if meta.get("scratch", 0) != 0:
         bad.append(f"kernel uses {meta['scratch']} B/lane of scratch: a spilled asynchronous destination would be stale")
+    if meta.get("vgprs", 0) > 168:
+        bad.append(f"kernel uses {meta['vgprs']} VGPRs: more than the 168 that 3 waves/SIMD allow (csrc/bsdfd.hip, BSDFD_MIN_WAVES)")
     return n_async, bad
 
 
