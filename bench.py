@@ -522,6 +522,17 @@ def worker(a):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    # `multi`: run the N > 1 control flow (process group, barriers, the three gather modes).  Always for N > 1; at N = 1 only
+    # when BSDFD_BENCH_FORCE_PG=1 — a one-rank process group over the REAL backend, which is how the RCCL branch of this file
+    # (communicator set-up, device-side gather, all-reduce of the step size) is exercised on a 1-GPU box
+    # (tests/test_gpu_bench.py::test_bench_rccl_branch_with_one_rank)
+    multi = world > 1 or os.environ.get("BSDFD_BENCH_FORCE_PG") == "1"
+    # stdout carries the ONE JSON line and nothing else: native libraries write there too (RCCL prints a version banner at
+    # communicator set-up on this image), so fd 1 is pointed at stderr for the rest of the process and the line goes to the
+    # saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     # one process per GPU; BSDFD_BENCH_BACKEND=gloo is a TEST hook (several ranks sharing the one GPU of a 1-GPU box,
     # gather staged through host memory) that exercises the N>1 control flow without RCCL
     backend = os.environ.get("BSDFD_BENCH_BACKEND", "nccl")
@@ -536,7 +547,12 @@ def worker(a):
     dev_index = local_rank % n_dev  # (only the gloo test hook ever wraps: several ranks sharing the one GPU of a 1-GPU box)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    if multi and world == 1:  # forced one-rank group without a launcher: supply the rendezvous ourselves
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if multi:
         import datetime
         tmo = datetime.timedelta(seconds=float(os.environ.get("BSDFD_BENCH_PG_TIMEOUT_S", "180")))
         if backend == "nccl":
@@ -550,7 +566,7 @@ def worker(a):
     # rank passes the same barrier whether or not a build was needed
     if rank == 0 and not os.path.exists(_lib.LIB_PATH):
         _lib.build(verbose=True)
-    if world > 1:
+    if multi:
         dist.barrier()
 
     wl = make_workload(a.workload, device, rank, a.precision)
@@ -558,7 +574,7 @@ def worker(a):
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -566,14 +582,14 @@ def worker(a):
     settle(wl, a.settle_ms)
     t_pass = pass_seconds(wl)
     R = a.passes_per_step or max(1, int(math.ceil(MIN_TIMED_S / (max(a.steps, 1) * max(t_pass, 1e-6)))))
-    if world > 1:
+    if multi:
         t = torch.tensor([R], dtype=torch.int64, device=stage)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         R = int(t.item())
 
     gather_out = ([torch.empty((n_local, 4), dtype=torch.float32, device=stage) for _ in range(world)]
-                  if (world > 1 and rank == 0) else None)
-    comm = torch.cuda.Stream(device) if world > 1 else None
+                  if (multi and rank == 0) else None)
+    comm = torch.cuda.Stream(device) if multi else None
 
     def gather_now():
         dist.gather(wl.result().to(stage), gather_out, dst=0)
@@ -602,7 +618,7 @@ def worker(a):
             torch.cuda.current_stream().wait_stream(comm)
         fence()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             tt = torch.tensor([dt], dtype=torch.float64, device=stage)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -610,16 +626,16 @@ def worker(a):
 
     for k in range(a.warmup * R):
         wl.run_pass(k)
-    if world > 1:
+    if multi:
         gather_now()  # also initialises the communicator outside the timed region
-    judged_mode = a.gather if world > 1 else "none"
+    judged_mode = a.gather if multi else "none"
     profiling(wl, True)
     dt = region(judged_mode, a.warmup * R)
     n_launch, kern_ms = profile_read(wl)
     profiling(wl, False)
     wl.check()
     extra_regions = {}
-    if world > 1:
+    if multi:
         for mode in ("none", "final", "every"):
             if mode != judged_mode:
                 extra_regions[mode] = region(mode, (a.warmup + a.steps) * R)
@@ -627,7 +643,7 @@ def worker(a):
     props = torch.cuda.get_device_properties(dev_index)
     ranks_info = [{"rank": rank, "local_rank": local_rank, "device": dev_index, "name": torch.cuda.get_device_name(dev_index),
                    "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None)}]
-    if world > 1:
+    if multi:
         gathered = [None] * world
         dist.all_gather_object(gathered, ranks_info[0])
         ranks_info = gathered
@@ -654,11 +670,11 @@ def worker(a):
                                        ("" if world == 1 else {"final": "; one RCCL gather-to-root of the final (wo,pdf) shards inside the timed region",
                                                                "every": "; RCCL gather-to-root every step, overlapped on a side stream",
                                                                "none": "; results left device-resident"}[judged_mode]),
-                           ranks=ranks_info, backend=backend if world > 1 else None,
-                           rccl_ranks=world if (world > 1 and backend == "nccl") else 0,
+                           ranks=ranks_info, backend=backend if multi else None,
+                           rccl_ranks=world if (multi and backend == "nccl") else 0,
                            distinct_devices=len({(r_["device"], r_.get("uuid")) for r_ in ranks_info})),
         }
-        if world > 1:
+        if multi:
             rates = {judged_mode: queries_timed / dt / 1e6}
             rates.update({m: queries_timed / t / 1e6 for m, t in extra_regions.items()})
             out["multi_gpu"] = {"Msamples_per_s_no_gather": rates["none"], "Msamples_per_s_final_gather": rates["final"],
@@ -767,8 +783,8 @@ def worker(a):
             out["cpu_baseline"] = cpu_baseline(wl.material, wl.domain, wl.T)
         elif world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline("aniso_miro_7_rgb", "disk", 4)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if multi:
         dist.barrier()  # orderly teardown: rank 0 is still printing / timing its side figures
         dist.destroy_process_group()
     return 0

@@ -112,3 +112,18 @@ def test_bench_refuses_to_oversubscribe_gpus_under_rccl():
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert "refusing to oversubscribe" in (r.stdout + r.stderr)
+
+
+def test_bench_rccl_branch_with_one_rank():
+    """Every N > 1 test above runs over gloo (several ranks cannot share one GPU under RCCL).  BSDFD_BENCH_FORCE_PG=1 makes a
+    ONE-rank run go through the whole multi-rank control flow over the real backend: `init_process_group("nccl")` = RCCL
+    communicator set-up on the device, device-side `dist.gather` of the (wo, pdf) shards in the three gather modes, the
+    all-reduces of the step size and of the max-over-ranks time.  What stays unexercised on a 1-GPU box is only the transport
+    between GPUs."""
+    d = _run(["--gpus", "1"] + FAST, {"BSDFD_BENCH_FORCE_PG": "1"})
+    _check_contract(d, 1, "disk_1Mi_T8")
+    assert d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1 and d["config"]["distinct_devices"] == 1
+    mg = d["multi_gpu"]
+    assert mg["judged"] == "final" and mg["Msamples_per_s_no_gather"] > 0 and mg["Msamples_per_s_gather_every_step_overlapped"] > 0
+    plain = _run(["--gpus", "1"] + FAST)
+    assert 0.5 * plain["value"] < mg["Msamples_per_s_no_gather"] < 1.5 * plain["value"]
