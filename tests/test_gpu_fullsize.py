@@ -60,6 +60,12 @@ def test_full_size_properties(stem, domain, n, T):
     ok = (pdf > 1e-3) & (p > 1e-3)
     ratio = (p[ok] / pdf[ok]).cpu().numpy()
     assert 0.8 < np.median(ratio) < 1.25
+    # per-query context at full size: sample() writes it, pdf() of the same wavefront reads it — not a bit moves
+    ctx = s.new_context(n)
+    wo_c, pdf_c = s.plugin_sample(wi, None, T=T, seed=99, ctx_out=ctx)
+    assert torch.equal(wo_c, wo) and torch.equal(pdf_c, pdf)
+    assert torch.equal(s.plugin_pdf(wi, wo, T=T, ctx_in=ctx), p)
+    del ctx, wo_c, pdf_c
     # oracle on a random subsample, with the base draw injected so both sides flow the same x0
     idx = torch.randperm(n, generator=torch.Generator().manual_seed(5))[:4096]
     wis = wi[idx.to(_dev())].contiguous()
