@@ -36,6 +36,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import weights as W
 from .sharding import shard_range
 
 
@@ -170,9 +171,18 @@ class WavefrontRenderer:
         # sample(): Philox counter = global path index, key = (seed, pass) -> independent of the row split
         offset = row_begin * self.camera.width * spp
         skey = (seed * 0x9E3779B97F4A7C15 + pass_idx + 1) & 0xFFFFFFFFFFFFFFFF
-        # one launch for sample(wi) and pdf(wi, wl): the per-intersection prologue is shared
-        core.sampler.plugin_sample_pdf(b["wi"], b["wl"], x0, T=core.T, variant=core.VARIANT, seed=skey, offset=offset,
-                                       out=(b["wo"], b["pdf_o"], b["pdf_l"]))
+        if core.DOMAIN == W.DOMAIN_DISK:
+            # one launch for sample(wi) and pdf(wi, wl): the per-intersection prologue is shared in registers
+            core.sampler.plugin_sample_pdf(b["wi"], b["wl"], x0, T=core.T, variant=core.VARIANT, seed=skey, offset=offset,
+                                           out=(b["wo"], b["pdf_o"], b["pdf_l"]))
+        else:
+            # spherical nets: the single-op kernels form the Jacobian by meeting in the middle, the fused instantiation could not
+            # (register budget) — two launches that share the prologue through the per-query context are the faster pair
+            if "ctx" not in b:
+                b["ctx"] = core.sampler.new_context(n)
+            core.sampler.plugin_sample(b["wi"], x0, T=core.T, variant=core.VARIANT, seed=skey, offset=offset,
+                                       out=(b["wo"], b["pdf_o"]), ctx_out=b["ctx"])
+            core.sampler.plugin_pdf(b["wi"], b["wl"], T=core.T, variant=core.VARIANT, out=b["pdf_l"], ctx_in=b["ctx"])
         if self.use_ground_truth:  # eval() of the reference's loop: f cos (albedo-tinted) for both strategies
             core.bsdf.eval_t(b["wi"], b["wo"], out=b["f_o"], tint=core.albedo)
             core.bsdf.eval_t(b["wi"], b["wl"], out=b["f_l"], tint=core.albedo)
