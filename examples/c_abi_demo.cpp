@@ -81,6 +81,24 @@ int main(int argc, char** argv) {
     for (long long i = 0; i < n; ++i) diff += pp2[i] != pp[i];
     std::printf("graph : %lld of %lld pdf values differ from the eager run\n", diff, n);
     HIPCHECK(hipGraphExecDestroy(exec)); HIPCHECK(hipGraphDestroy(graph));
+
+    // sample(wi) then pdf(wi, .) for the SAME intersections: hand the per-query context over (bsdfd_opts, *_ex calls)
+    void* d_ctx = nullptr;
+    const long long ctx_bytes = bsdfd_context_bytes(h, n, 1);
+    HIPCHECK(hipMalloc(&d_ctx, (size_t)ctx_bytes));
+    bsdfd_opts o = {};
+    o.ctx_out = d_ctx;
+    CHECK(bsdfd_plugin_sample_ex(h, BSDFD_PLUGIN_MEASURED, d_wi, nullptr, 7, 0, n, T, d_wo, d_ps, &o, st));
+    o.ctx_out = nullptr; o.ctx_in = d_ctx;
+    HIPCHECK(hipMemsetAsync(d_pp, 0, 4 * n, st));
+    CHECK(bsdfd_plugin_pdf_ex(h, BSDFD_PLUGIN_MEASURED, d_wi, d_wo, n, T, d_pp, &o, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    std::vector<float> pp3(n);
+    HIPCHECK(hipMemcpy(pp3.data(), d_pp, 4 * n, hipMemcpyDeviceToHost));
+    long long diff_ctx = 0;
+    for (long long i = 0; i < n; ++i) diff_ctx += pp3[i] != pp[i];
+    std::printf("ctx   : %lld B of per-query context; %lld of %lld pdf values differ from the eager run\n", ctx_bytes, diff_ctx, n);
+    HIPCHECK(hipFree(d_ctx));
     bsdfd_destroy(h);
-    return diff == 0 && pos > n / 2 && norm_err < 1e-4 ? 0 : 1;
+    return diff == 0 && diff_ctx == 0 && pos > n / 2 && norm_err < 1e-4 ? 0 : 1;
 }

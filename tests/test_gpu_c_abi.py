@@ -23,7 +23,8 @@ def test_c_abi_demo_builds_and_runs(tmp_path):
     for mat, dom in (("aniso_miro_7_rgb", "disk"), ("chm_orange_rgb", "spherical")):
         r = subprocess.run([exe, W.shipped_path(mat, dom), "200000"], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
-        assert "0 of 200000 pdf values differ" in r.stdout, r.stdout
+        assert "graph : 0 of 200000 pdf values differ" in r.stdout, r.stdout
+        assert "of per-query context; 0 of 200000 pdf values differ" in r.stdout, r.stdout   # bsdfd_opts / *_ex from plain C++
     r = subprocess.run([exe, "/nonexistent.bsdfw"], capture_output=True, text=True)
     assert r.returncode != 0 and "cannot open" in r.stderr
 
