@@ -1343,8 +1343,8 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
         const int o_wg = fold ? (sp ? o_wfl + 2 * NM * fr : o_wfl) : o_wo + fr, o_wgl = o_wg + 2 * NM * fr;
         if (L.wh != o_wh || L.wh_lo != o_whl || L.wo != o_wo || L.wf != o_wf || L.wf_lo != o_wfl || L.wg != o_wg ||
             L.wg_lo != o_wgl) {
-            std::fprintf(stderr, "bsdfd: weight-image layout drifted from the kernel's compile-time offsets\n");
-            std::abort();
+            L.total = -1;  // reported by bsdfd_create as an error: never launch a kernel whose fragment offsets are wrong
+            return {};
         }
     }
     L.bw1 = off; off += (BASE_PE_BANDS + 1) * 64 * 4;
@@ -1693,6 +1693,10 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     h->n_rec = h->n_done = 0; h->total_ms = 0.0; h->last_ms = -1.0f;
     for (int i = 0; i < bsdfd_ctx::RING; ++i) { h->pending[i] = false; h->ev0[i] = nullptr; h->ev1[i] = nullptr; }
     std::vector<char> img = build_image(*d, prec, h->L);
+    if (h->L.total < 0) {
+        delete h;
+        return fail(BSDFD_EINVAL, "internal error: weight-image layout differs from the kernel's compile-time fragment offsets");
+    }
     if (h->L.total > 160 * 1024 - 512) {
         delete h;
         return fail(BSDFD_EINVAL, "weight image does not fit the 160 KiB LDS; use fewer layers or BSDFD_PREC_F16");
