@@ -1479,6 +1479,13 @@ const void* kernel_ptr(int domain, int nm, int n_hidden, int prec, int mode) {
     return kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 4, 0>(prec, mode);
 }
 inline int threads_for(int nm) { return nm == 2 ? 256 : 512; }
+// extra dynamic LDS per workgroup: 0 in the product; a tools build (tools/tuning_knobs.h) reads $BSDFD_LDS_PAD to lower the
+// number of resident workgroups per CU (occupancy sweeps of the same binary)
+#ifdef BSDFD_TOOLS_LDS_PAD
+inline size_t lds_pad() { BSDFD_TOOLS_LDS_PAD }
+#else
+constexpr size_t lds_pad() { return 0; }
+#endif
 
 hipError_t harvest(bsdfd_handle h, int slot) {
     hipError_t e = hipEventSynchronize(h->ev1[slot]);
@@ -1617,7 +1624,7 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
             HIP_TRY(hipEventRecord(h->ev0[slot], s));
         }
     }
-    hipError_t e = hipLaunchKernel(h->kfun[mode], grid, block, args, (size_t)h->L.total, s);
+    hipError_t e = hipLaunchKernel(h->kfun[mode], grid, block, args, (size_t)h->L.total + lds_pad(), s);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) return fail(BSDFD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     if (slot >= 0) {
@@ -1710,10 +1717,10 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     for (int jac = 0; jac < 3 && e == hipSuccess; ++jac) {
         h->kfun[jac] = kernel_ptr(h->domain, h->width / 16, h->n_hidden, prec, jac);
         // dynamic LDS above the default cap needs the attribute (per function and device)
-        e = hipFuncSetAttribute(h->kfun[jac], hipFuncAttributeMaxDynamicSharedMemorySize, h->L.total);
+        e = hipFuncSetAttribute(h->kfun[jac], hipFuncAttributeMaxDynamicSharedMemorySize, h->L.total + (int)lds_pad());
         int nb = 0;
         if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h->kfun[jac], threads_for(h->width / 16), (size_t)h->L.total);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h->kfun[jac], threads_for(h->width / 16), (size_t)h->L.total + lds_pad());
         h->per_cu[jac] = nb;
     }
     if (e != hipSuccess) {

@@ -13,3 +13,10 @@
         return ov ? std::atoi(ov) : -1;                                    \
     }();                                                                   \
     if (per_cu_override > 0) per_cu = per_cu_override;
+// $BSDFD_LDS_PAD: extra bytes of dynamic LDS per workgroup (fewer resident workgroups per CU: occupancy sweeps)
+#define BSDFD_TOOLS_LDS_PAD                                                \
+    static const size_t pad = [] {                                         \
+        const char* ov = std::getenv("BSDFD_LDS_PAD");                     \
+        return ov ? (size_t)std::atoll(ov) : (size_t)0;                    \
+    }();                                                                   \
+    return pad;
