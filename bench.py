@@ -403,6 +403,19 @@ def profile_read(wl):
     return n_tot, ms_tot
 
 
+def profile_clock_mhz(wl):
+    """Shader clock (MHz) the chip sustained under the profiled launches themselves (bsdfd_profile_clock_mhz: the waves' own
+    shader-cycle over wall-clock counters), launch-time-weighted over the handles of the workload."""
+    num, den = 0.0, 0.0
+    for s in wl.samplers:
+        n, ms = s.profile_read()
+        mhz = s.profile_clock_mhz()
+        if n and mhz > 0:
+            num += mhz * ms
+            den += ms
+    return num / den if den > 0 else None
+
+
 def settle(wl, ms):
     """Setup, untimed: leave the idle power state (tools/ramp.py: the first ~30 ms after idle the same kernel takes
     645 us instead of 545 us); results are discarded."""
@@ -470,16 +483,13 @@ def run_secondary(name, device, precision):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     n_launch, kern_ms = profile_read(wl)
+    mhz = profile_clock_mhz(wl)  # the clock of the timed launches themselves (in-kernel shader-cycle stamps / HIP-event time)
     profiling(wl, False)
     wl.check()
-    try:
-        from bsdf_diffusion_sampling_amd import _lib
-        mhz = _lib.shader_clock_mhz()  # right after the timed passes: the clock this workload ran at
-    except Exception:
-        mhz = None
     out = {"workload": name, "value": wl.n_local * reps / dt / 1e6, "unit": "Msamples/s", "passes": reps,
            "ms_per_pass": dt / reps * 1e3, "kernel_ms_per_pass": kern_ms / reps, "launches_per_pass": n_launch / reps,
            "avg_launch_ms": kern_ms / max(n_launch, 1), "shader_clock_mhz": mhz,
+           "shader_clock_basis": "the timed launches' own shader-cycle / wall-clock counters, every wave (bsdfd_profile_clock_mhz)",
            "algorithmic_TFLOPs_wall": wl.flops_per_pass * reps / dt / 1e12,
            "frac": wl.flops_per_pass * reps / (kern_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
            "frac_basis": "algorithmic flop / summed flow-kernel time (HIP events) / 2500 TFLOP/s",
@@ -632,6 +642,7 @@ def worker(a):
     profiling(wl, True)
     dt = region(judged_mode, a.warmup * R)
     n_launch, kern_ms = profile_read(wl)
+    kern_mhz = profile_clock_mhz(wl)   # the clock of the judged launches themselves (in-kernel cycle stamps / HIP-event time)
     profiling(wl, False)
     wl.check()
     extra_regions = {}
@@ -724,23 +735,50 @@ def worker(a):
                          "pdf_Msamples_per_s": n_local / (split["pdf"] * 1e-3) / 1e6})
             # issue-bound view: measured SIMD cycles per (16-query tile x Euler step) vs the instruction-issue model
             try:
-                mhz = _lib.shader_clock_mhz()
+                probe_mhz = _lib.shader_clock_mhz()
+                mhz = kern_mhz or probe_mhz
                 n_simd = torch.cuda.get_device_properties(dev_index).multi_processor_count * 4
                 tiles = n_local / 16
                 meas = avg_ms * 1e-3 * mhz * 1e6 * n_simd / (tiles * wl.T)
+                # loop-only: the same sample launch at T and 2T (outside the timed region) — the per-query prologue cancels
+                loop = {}
+                for TT in (wl.T, 2 * wl.T):
+                    for k in range(6):
+                        wl.smp.plugin_sample(wl.wi, None, T=TT, variant=wl.variant, seed=5 + k, out=(wl.wo[0], wl.pdf_s[0]))
+                    torch.cuda.synchronize()
+                    profiling(wl, True)
+                    for k in range(12):
+                        wl.smp.plugin_sample(wl.wi, None, T=TT, variant=wl.variant, seed=50 + k, out=(wl.wo[0], wl.pdf_s[0]))
+                    _, ms_tt = profile_read(wl)
+                    loop[TT] = (ms_tt / 12, profile_clock_mhz(wl))
+                    profiling(wl, False)
+                # (each launch length is converted at the clock ITS launches ran at: the two may differ by a few per cent)
+                c_long = loop[2 * wl.T][0] * (loop[2 * wl.T][1] or mhz)
+                c_short = loop[wl.T][0] * (loop[wl.T][1] or mhz)
+                loop_mhz = loop[2 * wl.T][1] or mhz
+                meas_loop = (c_long - c_short) / wl.T * 1e-3 * 1e6 * n_simd / tiles
                 ib = {"shader_clock_mhz": mhz, "simds": n_simd,
+                      "shader_clock_basis": "the judged launches' own shader-cycle / wall-clock counters, every wave "
+                                            "(bsdfd_profile_clock_mhz); `probe_clock_mhz` is the stand-alone probe kernel (csrc/clock.hip), "
+                                            "a similar instruction mix but not the kernel itself",
+                      "probe_clock_mhz": probe_mhz,
                       "measured_simd_cycles_per_tile_step": meas,
-                      "note": "measured = avg launch time x clock x SIMDs / (tiles x T), so it carries the per-query prologue's "
-                              "share; model = occupancy of the SIMD's VALU issue path summed over the loop's instructions "
-                              "(tools/isa_mix.py on the shipped build; a 16x16x32 MFMA holds that path ~9.6 of its 16 matrix-pipe "
-                              "cycles, a transcendental ~11 cycles between plain VALU: tools/ubench/RESULTS.md round 3) — "
-                              "model/measured ~ 1 means the kernel runs at its issue bound"}
+                      "measured_loop_cycles_per_tile_step": meas_loop,
+                      "loop_basis": f"(sample launch at T={2 * wl.T} minus at T={wl.T}) / {wl.T}: {loop[2 * wl.T][0]:.4f} ms, {loop[wl.T][0]:.4f} ms "
+                                    f"at {loop_mhz:.0f} and {(loop[wl.T][1] or mhz):.0f} MHz — the per-query prologue and epilogue cancel",
+                      "note": "measured_simd_cycles = avg launch time x clock x SIMDs / (tiles x T) carries the per-query prologue's "
+                              "share; measured_loop_cycles is the Euler step alone and is what the model describes.  Model = sum over "
+                              "the loop's instructions of what each costs the SIMD (tools/isa_mix.py on the shipped build): in this "
+                              "VALU-heavy mix MFMA time and VALU time add — a 16x16x32 MFMA 16.4 cycles, a transcendental ~11 between "
+                              "plain VALU (tools/ubench/RESULTS.md rounds 3-4) — model/measured_loop ~ 1 means the step runs at the "
+                              "hardware's issue rate for this instruction mix"}
                 mdl, mdl_prov = isa_model(a.workload)
                 ib["model_source"] = mdl_prov
                 if mdl:
                     ib.update({"model_issue_cycles_per_tile_step": mdl["issue_cycles_total"], "model_mfma_cycles": mdl["issue_cycles_mfma"],
                                "model_valu_cycles": mdl["issue_cycles_valu"], "n_mfma": mdl["n_mfma"], "n_valu": mdl["n_valu"],
-                               "frac_of_issue_bound": mdl["issue_cycles_total"] / meas})
+                               "frac_of_issue_bound": mdl["issue_cycles_total"] / meas_loop,
+                               "frac_of_issue_bound_basis": "model / measured_loop_cycles_per_tile_step"})
                 roof["issue_bound"] = ib
             except Exception as exc:
                 roof["issue_bound"] = {"error": repr(exc)}

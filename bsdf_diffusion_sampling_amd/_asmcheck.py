@@ -1,0 +1,147 @@
+"""Safety check of the flow kernels' asynchronous LDS reads on the gfx950 assembly of a build (pure text analysis, no GPU).
+
+csrc/bsdfd.hip fetches weight fragments with inline-asm ``ds_read_b128`` whose destination registers the compiler believes
+valid at once; they only become valid at the following ``s_waitcnt lgkmcnt(0)``.  Whether the code between a read and its
+wait leaves those registers alone is a property of the compiler's register allocation and scheduling, i.e. of the toolchain
+that builds the library — so ``_lib.build()`` runs this check on the assembly of the very compilation it ships and falls back
+to the ``-DBSDFD_NO_ASYNC_LDS`` variant (ordinary compiler-managed LDS loads) when it fails.  ``tools/isa_mix.py
+--check-async`` is the command-line front end.
+"""
+from __future__ import annotations
+
+import collections
+import re
+from typing import Dict, List, Tuple
+
+
+def kernel_body(lines: List[str], key: str) -> List[str]:
+    start = None
+    for i, l in enumerate(lines):
+        if l.startswith("_Z") and key in l and l.split(";")[0].rstrip().endswith(":"):
+            start = i
+            break
+    if start is None:
+        raise KeyError(f"kernel matching {key!r} not found")
+    for j in range(start, len(lines)):
+        if lines[j].strip().startswith("s_endpgm"):
+            return lines[start:j + 1]
+    return lines[start:]
+
+
+def kernel_names(lines: List[str], fragment: str = "flow_kernel") -> List[str]:
+    """Mangled names of every kernel in the file whose name contains ``fragment``."""
+    out = []
+    for l in lines:
+        if l.startswith("_Z") and fragment in l and l.split(";")[0].rstrip().endswith(":"):
+            out.append(l.split(":")[0].strip())
+    return out
+
+
+def loops(body: List[str]) -> List[Tuple[int, int]]:
+    """(first, last) line indices of every label .. backward-branch pair."""
+    labels, out = {}, []
+    for i, l in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            labels[m.group(1)] = i
+        m = re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels:
+            out.append((labels[m.group(1)], i))
+    return out
+
+
+def mix(body: List[str], lo: int, hi: int) -> collections.Counter:
+    c = collections.Counter()
+    for l in body[lo:hi + 1]:
+        l = l.split(";")[0].strip()
+        if not l or l.endswith(":") or l.startswith("."):
+            continue
+        c[re.sub(r"_(e32|e64|sdwa|dpp)$", "", l.split()[0])] += 1
+    return c
+
+
+def euler_loop(body: List[str]):
+    """The Euler-step loop = the SHORTEST loop that holds at least half of the MFMAs of the MFMA-richest loop (the tile loop
+    around it holds the prologue's MFMAs as well).  None if the kernel has no loop with MFMAs."""
+    cand = []
+    for lo, hi in loops(body):
+        c = mix(body, lo, hi)
+        cand.append((sum(v for k, v in c.items() if k.startswith("v_mfma")), hi - lo, (lo, hi)))
+    if not cand or max(n for n, _, _ in cand) == 0:
+        return None
+    top = max(n for n, _, _ in cand)
+    return min((span, rng) for n, span, rng in cand if 2 * n >= top)[1]
+
+
+def _regs(tok: str) -> set:
+    """VGPR indices named by an operand token: v12 -> {12}, v[4:7] -> {4..7}."""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def kernel_meta(lines: List[str], key: str) -> Dict[str, int]:
+    meta = {}
+    for i, l in enumerate(lines):
+        if ".name:" in l and key in l:
+            for l2 in lines[i:i + 16]:
+                for f in ("vgpr_count", "sgpr_count", "vgpr_spill_count", "private_segment_fixed_size"):
+                    m = re.search(rf"\.{f}:\s+(\d+)", l2)
+                    if m:
+                        meta[f] = int(m.group(1))
+            break
+    return meta
+
+
+def check_async_lines(lines: List[str], key: str) -> Tuple[int, List[str]]:
+    """(number of asynchronous reads, violations) of one kernel.  A violation is
+    * an instruction — spill stores and reloads included — that reads or writes a destination register of an asynchronous
+      read before the next ``s_waitcnt lgkmcnt(0)``,
+    * control flow with destinations still pending, or
+    * spill traffic inside the Euler-step loop of a kernel that uses asynchronous reads."""
+    body = kernel_body(lines, key)
+    bad, pending, in_asm, n_async = [], {}, False, 0
+    for i, raw in enumerate(body):
+        l = raw.strip()
+        if l.startswith(";;#ASMSTART") or l.startswith(";#ASMSTART"):
+            in_asm = True
+            continue
+        if l.startswith(";;#ASMEND") or l.startswith(";#ASMEND"):
+            in_asm = False
+            continue
+        code = l.split(";")[0].strip()
+        if not code or code.endswith(":") or code.startswith("."):
+            continue
+        op = code.split()[0]
+        toks = [t.strip(",") for t in code.split()[1:]]
+        if op.startswith("s_waitcnt") and "lgkmcnt(0)" in code:
+            pending.clear()
+            continue
+        touched = set().union(*[_regs(t) for t in toks]) if toks else set()
+        for r in touched & set(pending):
+            bad.append(f"line {i}: `{code}` touches v{r}, the destination of the asynchronous read at line {pending[r]}")
+        if in_asm and op == "ds_read_b128":
+            n_async += 1
+            for r in _regs(toks[0]):
+                pending[r] = i
+        if op.startswith("s_cbranch") or op.startswith("s_branch") or op == "s_endpgm":
+            if pending:
+                bad.append(f"line {i}: control flow `{code}` with {len(pending)} asynchronous destination registers still pending")
+                pending.clear()
+    if n_async:
+        rng = euler_loop(body)
+        if rng is not None:
+            n_in = sum(1 for l in body[rng[0]:rng[1] + 1] if l.split(";")[0].strip().startswith("scratch_"))
+            if n_in:
+                bad.append(f"{n_in} scratch instructions inside the Euler-step loop")
+    return n_async, bad
+
+
+def check_file(path: str, fragment: str = "flow_kernel") -> Dict[str, Tuple[int, List[str]]]:
+    """Every kernel of the assembly file whose name contains ``fragment`` -> (asynchronous reads, violations)."""
+    lines = open(path).read().splitlines()
+    return {k: check_async_lines(lines, k) for k in kernel_names(lines, fragment)}

@@ -36,7 +36,7 @@ EXPORTS = (
     "bsdfd_gather_lanes", "bsdfd_scatter_lanes",
     "bsdfd_measured_create_from_file", "bsdfd_measured_destroy", "bsdfd_measured_get_info", "bsdfd_measured_eval",
     "bsdfd_measured_sample_weight",
-    "bsdfd_set_profiling", "bsdfd_profile_read", "bsdfd_last_kernel_ms", "bsdfd_shader_clock_mhz",
+    "bsdfd_set_profiling", "bsdfd_profile_read", "bsdfd_profile_clock_mhz", "bsdfd_last_kernel_ms", "bsdfd_shader_clock_mhz",
     "bsdfd_last_error", "bsdfd_version",
 )
 
@@ -73,26 +73,113 @@ class Desc(C.Structure):
                                                     "base_w2", "base_b2")]
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile libbsdfd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    hdr = os.path.join(INCLUDE_DIR, "bsdfd.h")
-    if (not force and os.path.exists(LIB_PATH)
-            and os.path.getmtime(LIB_PATH) >= max([os.path.getmtime(hdr)] + [os.path.getmtime(f) for f in DEP_PATHS])):
-        return LIB_PATH
-    # compile to a temporary name and rename into place: a concurrent process (another rank of a torchrun
-    # launch, a parallel test worker) never dlopens a half-written library
-    tmp = f"{LIB_PATH}.tmp.{os.getpid()}"
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed",
-           "-I", INCLUDE_DIR, *SRC_PATHS, "-o", tmp]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed",
+               "-Wno-unused-command-line-argument"]
+BUILD_INFO_PATH = LIB_PATH + ".build.json"   # which variant of the flow kernels the last build() shipped, and why
+
+
+def _check_asm(asm_path: str):
+    """Violations of the asynchronous-LDS-read discipline in the assembly of a compilation of csrc/bsdfd.hip
+    (``_asmcheck.check_file``): {kernel: [messages]} for the kernels that have any.  A seam of its own so that a test can
+    feed the build a doctored result."""
+    from . import _asmcheck
+    return {k: bad for k, (n, bad) in _asmcheck.check_file(asm_path).items() if bad}
+
+
+def _compile_flow_tu(td: str, extra, verbose: bool):
+    """Compile csrc/bsdfd.hip to td/bsdfd.o keeping the device assembly of THIS compilation (-save-temps=obj)."""
+    import glob
+    for f in glob.glob(os.path.join(td, "bsdfd*")):
+        os.remove(f)
+    cmd = ["hipcc", *HIPCC_FLAGS, *extra, "-save-temps=obj", "-I", INCLUDE_DIR, "-c", SRC_PATH, "-o", os.path.join(td, "bsdfd.o")]
     if verbose:
         print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=td)
+    asm = [f for f in glob.glob(os.path.join(td, "bsdfd*.s")) if "gfx950" in os.path.basename(f)]
+    if len(asm) != 1:
+        raise RuntimeError(f"expected one gfx950 assembly file from -save-temps, found {asm}")
+    return asm[0]
+
+
+def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> str:
+    """Compile libbsdfd.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    The flow kernels read their weight fragments with inline-asm LDS loads whose safety depends on the toolchain's register
+    allocation (csrc/bsdfd.hip, lds_read_b128_async_at), so the build verifies the assembly of its own compilation
+    (``_asmcheck``) and, if that fails, REBUILDS the kernels with ``-DBSDFD_NO_ASYNC_LDS`` (compiler-managed LDS loads, ~2 %
+    slower) instead of shipping a library that could read stale weights.  ``<lib>.build.json`` and ``bsdfd_version()`` say
+    which variant shipped."""
+    import json
+    import tempfile
+    out = lib_path or LIB_PATH
+    hdr = os.path.join(INCLUDE_DIR, "bsdfd.h")
+    deps = DEP_PATHS + [os.path.join(_HERE, "_asmcheck.py")]
+    if (not force and os.path.exists(out)
+            and os.path.getmtime(out) >= max([os.path.getmtime(hdr)] + [os.path.getmtime(f) for f in deps])):
+        return out
+    # compile to a temporary name and rename into place: a concurrent process (another rank of a torchrun
+    # launch, a parallel test worker) never dlopens a half-written library
+    tmp = f"{out}.tmp.{os.getpid()}"
+    info = {"variant": "async", "violations": {}, "hipcc": None}
     try:
-        subprocess.run(cmd, check=True)
-        os.replace(tmp, LIB_PATH)
-    finally:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-    return LIB_PATH
+        v = subprocess.run(["hipcc", "--version"], capture_output=True, text=True)
+        info["hipcc"] = next((l.strip() for l in v.stdout.splitlines() if "version" in l.lower()), None)
+    except OSError:
+        pass
+    with tempfile.TemporaryDirectory(prefix="bsdfd_build_") as td:
+        side = []
+        procs = []
+        for src in SRC_PATHS[1:]:   # the side translation units in parallel with the flow kernels
+            obj = os.path.join(td, os.path.basename(src)[:-4] + ".o")
+            side.append(obj)
+            cmd = ["hipcc", *HIPCC_FLAGS, "-I", INCLUDE_DIR, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+        try:
+            asm = _compile_flow_tu(td, [], verbose)
+            bad = _check_asm(asm)
+            if bad:
+                info["variant"], info["violations"] = "plain", {k: v[:8] for k, v in bad.items()}
+                print("=" * 100 + "\nbsdfd build: THIS TOOLCHAIN'S COMPILATION OF csrc/bsdfd.hip TOUCHES DESTINATION REGISTERS OF ASYNCHRONOUS "
+                      "LDS READS BEFORE THEIR WAIT:", flush=True)
+                for k, v in bad.items():
+                    print(f"  {k}: {len(v)} violation(s), e.g. {v[0]}", flush=True)
+                print("rebuilding the flow kernels with -DBSDFD_NO_ASYNC_LDS (compiler-managed LDS loads, ~2 % slower)\n" + "=" * 100,
+                      flush=True)
+                asm = _compile_flow_tu(td, ["-DBSDFD_NO_ASYNC_LDS"], verbose)
+                still = _check_asm(asm)
+                if still:
+                    raise RuntimeError(f"the fallback build still fails the assembly check: {still}")
+        finally:
+            for cmd, pr in procs:
+                if pr.wait() != 0:
+                    raise subprocess.CalledProcessError(pr.returncode, cmd)
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(td, "bsdfd.o"), *side, "-o", tmp]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        try:
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, out)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    with open(out + ".build.json", "w") as f:
+        json.dump(info, f, indent=1)
+    if verbose:
+        print(f"bsdfd build: shipped the {'asynchronous-LDS' if info['variant'] == 'async' else 'FALLBACK (compiler-managed LDS)'} "
+              f"variant of the flow kernels ({out})", flush=True)
+    return out
+
+
+def build_info(lib_path: str = None) -> dict:
+    """What the last ``build()`` of this library shipped: {"variant": "async" | "plain", "violations": {...}, "hipcc": ...}
+    (empty when the library was built some other way)."""
+    import json
+    try:
+        return json.load(open((lib_path or LIB_PATH) + ".build.json"))
+    except (OSError, ValueError):
+        return {}
 
 
 _lib = None
@@ -152,6 +239,7 @@ def lib():
     L.bsdfd_scatter_lanes.argtypes = [fp, i64, fp, fp, fp, fp, fp, fp, vp]
     L.bsdfd_set_profiling.argtypes = [vp, i32]
     L.bsdfd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]
+    L.bsdfd_profile_clock_mhz.argtypes = [vp, C.POINTER(C.c_double)]
     L.bsdfd_last_kernel_ms.argtypes = [vp]
     L.bsdfd_last_kernel_ms.restype = C.c_float
     L.bsdfd_shader_clock_mhz.argtypes = [C.POINTER(C.c_double), vp]

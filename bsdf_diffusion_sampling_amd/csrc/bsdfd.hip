@@ -26,7 +26,7 @@
 //   * the 2x2 Jacobian of the reference's two nets (disk 32x3, spherical 32x4) is formed by MEETING IN THE MIDDLE: the host
 //     also packs the output-side folded matrices G_j = W_L^T diag(Wout[j, :]); per step two tangent layers' worth of hi/lo
 //     splits, scalings and MFMAs are replaced by one fp32 2x2 bilinear form and a 5-swap cross-lane reduction (blocks
-//     "MIM" / "MIMS" in the Euler step; other depths / widths and the fused sample+pdf kernel run forward-mode tangents).
+//     "MIM" / "MIMS" in the Euler step; other depths / widths run forward-mode tangents).
 //   * a sample launch can write, and a pdf launch read, the per-query context (what depends on wi alone): bsdfd_opts.
 //   * precision of the contractions: exact fp32 MFMA (16x16x4), or fp16 MFMA (16x16x32)
 //     with hi+lo operand splitting (3 products, fp32 accumulate), or plain fp16.
@@ -70,7 +70,7 @@ constexpr int MAX_SEG = 64;  // materials per segmented launch (the descriptors 
 enum { IO_OPERATOR = 0, IO_PLUGIN = 1, IO_PLUGIN_FULLSPHERE = 2 };
 
 struct ImgLayout {  // byte offsets into the weight image (identical in global memory and LDS)
-    int win, wc, wh, wh_lo, wo, wf, wf_lo, wg, wg_lo, bw1, bb1, bw2, bb2, total;
+    int win, wc, wh, wh_lo, wo, wf, wf_lo, wg, wg_lo, bw1, bb1, bw2, bb2, wcs, wcs_lo, wt0, total;
 };
 
 struct KParams {
@@ -92,12 +92,17 @@ struct KParams {
     const float* in_c;   // OP_SAMPLE_PDF: wl [N,3], the direction whose pdf is asked
     float* out_pdf2;     // OP_SAMPLE_PDF: pdf(wi, wl) [N]
     // per-query context (everything derived from wi alone: conditioning term of layer 1 + base-net outputs), see
-    // bsdfd_context_bytes: written by a sample launch (ctx_out), read instead of recomputed by a pdf launch (ctx_in)
+    // bsdfd_context_bytes: written by whichever sample / pdf launch sees the wi array first (ctx_out), read instead of
+    // recomputed by the later ones (ctx_in)
     float* ctx_out;
     const float* ctx_in;
     // sample: Philox counter of row i = offset + rng_index[i] (NULL: offset + i).  A bucketed wavefront passes the rows'
     // ORIGINAL lane indices, so the draws do not depend on the bucketing, the sharding or the GPU count
     const long long* rng_index;
+    // profiling only (else NULL): every wave adds its lifetime in shader cycles (s_memtime) to clk[0] and in ticks of the
+    // constant-rate wall clock (s_memrealtime) to clk[1]; their ratio is the shader clock the kernel ran at
+    // (bsdfd_profile_clock_mhz).  Both counters are read by the same wave, so per-CU counter offsets cancel.
+    unsigned long long* clk;
     int seg_base;    // segmented launches: buckets served by EARLIER launches of the same call (context slot numbering)
     int chunk_log2;  // a wave takes 2^chunk_log2 consecutive-ish tiles per chunk (see the tile map in the kernel)
     int nseg;
@@ -177,7 +182,23 @@ __device__ __forceinline__ void sincos_enc(float a, float& s, float& c) {
 // LDS reads the compiler does not schedule or wait for: issued a phase ahead of their use and waited for just before the
 // first MFMA that consumes them (cdna_hip_programming.md §5.7, form (ii)).  hipcc itself places a ds_read right in front of
 // its use.  Until the wait statement the destination registers hold stale data although the compiler considers them defined:
-// tools/isa_mix.py --check-async verifies on the built assembly that nothing touches them in between.
+// whether the code in between leaves them alone depends on the toolchain's register allocation, so the BUILD checks it —
+// _lib.build() runs bsdf_diffusion_sampling_amd/_asmcheck.py on the assembly of the compilation it is about to ship and,
+// if any instruction touches a pending destination, recompiles this file with -DBSDFD_NO_ASYNC_LDS: the same reads as
+// ordinary loads the compiler schedules and waits for itself (~2 % slower, the round-3 `ab2_mim_first` form).
+#ifdef BSDFD_NO_ASYNC_LDS
+#define BSDFD_LDS_VARIANT "compiler-managed LDS reads (fallback build)"
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128_async_at(f16x8& dst, unsigned lane_base) {
+    typedef const f16x8 __attribute__((address_space(3))) * lds_frag_ptr;
+    dst = *reinterpret_cast<lds_frag_ptr>(static_cast<uintptr_t>(lane_base + (unsigned)OFF));
+}
+#define BSDFD_WAIT2(after, a, b) ((void)0)
+#define BSDFD_WAIT4(after, a, b, c, d) ((void)0)
+#define BSDFD_WAIT5(after, a, b, c, d, e) ((void)0)
+#define BSDFD_WAIT6(after, a, b, c, d, e, f) ((void)0)
+#else
+#define BSDFD_LDS_VARIANT "asynchronous LDS reads"
 template <int OFF>
 __device__ __forceinline__ void lds_read_b128_async_at(f16x8& dst, unsigned lane_base) {  // address = lane_base + OFF (immediate)
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lane_base), "n"(OFF) : "memory");
@@ -191,6 +212,7 @@ __device__ __forceinline__ void lds_read_b128_async_at(f16x8& dst, unsigned lane
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(after), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : : "memory")
 #define BSDFD_WAIT6(after, a, b, c, d, e, f) \
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(after), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : : "memory")
+#endif
 union Frag {  // one MFMA B fragment: the lane's 8 K-values of a chunk
     f16x8 v;
     f16x2 p[4];
@@ -304,6 +326,8 @@ __device__ __forceinline__ float von_mises_sample(float mu, float kappa, unsigne
 template <int DOMAIN, int NM, int PREC, bool JAC, int NH, bool FUSED>
 __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (p.clk) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     // this workgroup's share of the work: the whole batch, or one material's bucket
     const char* img = p.img;
     long long q_begin = 0, q_end = p.N;
@@ -339,10 +363,18 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
     // wanted 4 VGPRs more than 3 waves/SIMD allow; round 2 shipped a "PIN" arrangement (resident hi parts, the 4 folded lo
     // fragments fetched asynchronously per step: -3.7 %); MIM supersedes it (-5.7 % on top, profiles/r03_ab/).
     constexpr bool MIM = FOLD_L1 && KC == 1;
-    // the spherical 26-32x4-2 nets: two regular tangent layers, then the same meeting in the middle (block "MIMS" below);
-    // not in the fused sample+pdf instantiation, whose two-phase state leaves no room for the asynchronously fetched
-    // fragments (15 spilled VGPRs when tried — unsafe next to asynchronous destinations): it keeps forward-mode tangents
-    constexpr bool MIMS = JAC && NM == 2 && PREC != BSDFD_PREC_F32 && DOMAIN == BSDFD_DOMAIN_SPHERICAL && NH == 4 && !FUSED;
+    // the spherical 26-32x4-2 nets: two regular tangent layers, then the same meeting in the middle (block "MIMS" below).
+    // Round 4: also in the fused sample+pdf instantiation (-5.3 % kernel time, profiles/r04_ab/ab2*).  That kernel spills 16
+    // VGPRs, all in the per-tile prologue and at the phase switch — none inside the Euler loop and none between an
+    // asynchronous read and its wait, which is what tools/isa_mix.py --check-async verifies.
+    constexpr bool MIMS = JAC && NM == 2 && PREC != BSDFD_PREC_F32 && DOMAIN == BSDFD_DOMAIN_SPHERICAL && NH == 4;
+    // conditioning term of layer 1 on split-fp16 MFMAs: split3 builds of the DISK kernels (see the prologue).  Round 4,
+    // all 77 shipped sets x 2048 queries (profiles/r04_ab/acc_sweep_*.json): the worst disk set's p99 pdf error goes from 2.4e-5
+    // to 2.6e-5 (sample) and 2.3e-5 to 2.8e-5 (pdf) for -2.2 % kernel time at the plugin's T = 4 (-0.6 % at T = 8); the
+    // spherical nets would gain 0.5 % and lose margin (golden chm_orange pdf p99 5.1e-5 -> 8.2e-5 of the 1e-4 contract): they
+    // keep the exact-fp32 chains, as does every kernel in precision mode f32.
+    // (the samples-only split3 kernel follows, so that it walks exactly the trajectory of the sampling kernel)
+    constexpr bool SPLIT_PRO = PREC == BSDFD_PREC_SPLIT3 && DOMAIN == BSDFD_DOMAIN_DISK;
     const int n_hidden = NH ? NH : p.n_hidden;
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4;
@@ -361,6 +393,9 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
     const float* Lbb1 = reinterpret_cast<const float*>(smem + p.L.bb1);
     const float* Lbw2 = reinterpret_cast<const float*>(smem + p.L.bw2);
     const float* Lbb2 = reinterpret_cast<const float*>(smem + p.L.bb2);
+    const char* Lwcs = smem + p.L.wcs;
+    const char* Lwcs_lo = smem + p.L.wcs_lo;
+    const f32x4* Lwt0 = reinterpret_cast<const f32x4*>(smem + p.L.wt0);
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     float win[NM];
@@ -406,9 +441,21 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
         float y0 = 0.f, y1 = 0.f, wi_z = 1.0f;
         float xs0 = 0.f, xs1 = 0.f, wo_z = 1.0f, wo_sin = 1.0f;  // pdf: the point the reverse flow starts from
         float xi0 = 0.f, xi1 = 0.f;                              // sample: injected x0 (if any)
-        // per-query context: a pdf launch that is handed the context a sample launch wrote for the SAME wi array skips
-        // everything below that depends on wi alone (cart_to_spher(wi), encoding, conditioning term, base net)
+        // per-query context: a launch that is handed the context an earlier sample / pdf launch wrote for the SAME wi array
+        // skips everything below that depends on wi alone (cart_to_spher(wi), encoding, conditioning term, base net)
         const bool have_ctx = !FUSED && p.ctx_in != nullptr;
+        auto load_dir = [&](const float* dir) {  // plugin io: the direction whose pdf is asked -> start point of the reverse flow
+            const float ox = dir[qi * 3 + 0], oy = dir[qi * 3 + 1], oz = dir[qi * 3 + 2];
+            wo_z = oz;
+            wo_sin = sqrtf(ox * ox + oy * oy);  // Mitsuba Frame3f::sin_theta
+            if (DOMAIN == BSDFD_DOMAIN_DISK) {
+                xs0 = ox; xs1 = oy;
+            } else {
+                const float r = sqrtf(ox * ox + oy * oy + oz * oz);
+                xs0 = acosf(oz / (r + 1e-8f));
+                xs1 = atan2f(oy, ox);
+            }
+        };
         if (p.io == IO_OPERATOR) {
             const float2 c2 = reinterpret_cast<const float2*>(p.in_a)[qi];
             y0 = c2.x; y1 = c2.y;
@@ -426,19 +473,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
                 y0 = acosf(wz / (r + 1e-8f));
                 y1 = atan2f(wy, wx);
             }
-            if (FUSED || p.op == OP_PDF) {
-                const float* dir = FUSED ? p.in_c : p.in_b;
-                const float ox = dir[qi * 3 + 0], oy = dir[qi * 3 + 1], oz = dir[qi * 3 + 2];
-                wo_z = oz;
-                wo_sin = sqrtf(ox * ox + oy * oy);  // Mitsuba Frame3f::sin_theta
-                if (DOMAIN == BSDFD_DOMAIN_DISK) {
-                    xs0 = ox; xs1 = oy;
-                } else {
-                    const float r = sqrtf(ox * ox + oy * oy + oz * oz);
-                    xs0 = acosf(oz / (r + 1e-8f));
-                    xs1 = atan2f(oy, ox);
-                }
-            }
+            if (!FUSED && p.op == OP_PDF) load_dir(p.in_b);  // (the fused kernel loads wl at its phase switch: 4 registers less across phase 1)
             if ((FUSED || p.op != OP_PDF) && p.in_b != nullptr) {  // injected base sample
                 const float2 b2 = reinterpret_cast<const float2*>(p.in_b)[qi];
                 if (FUSED) { xi0 = b2.x; xi1 = b2.y; } else { xs0 = b2.x; xs1 = b2.y; }
@@ -492,10 +527,9 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
 
         // conditioning part of layer 1 (constant across the Euler steps) and the base-density net
         // PE_3 -> 16 (SiLU) -> 4, once per query
-        // c = W1[:, PE] PE(omega_i): exact fp32 MFMA chains (K = 4 slabs) in EVERY precision mode — this
-        // term enters z1 of all T steps, so its rounding error is systematic: an fp16-split version
-        // saved ~12 us per 1 Mi queries but raised the p99 pdf error from 1.8e-5 to 2.9e-5 (the MFMA's
-        // fp16 adder tree is not an fp32 FMA chain).  The NM chains (and the base net's) are issued
+        // c = W1[:, PE] PE(omega_i): exact fp32 MFMA chains (K = 4 slabs), except in the split3 disk kernels (SPLIT_PRO) — this
+        // term enters z1 of all T steps, so its rounding error is systematic (the MFMA's fp16 adder tree is not an fp32 FMA
+        // chain): see the accuracy sweep quoted at SPLIT_PRO.  The NM chains (and the base net's) are issued
         // slab-major so that consecutive MFMAs are independent (40-cycle dependent latency).
         // The base net (PE_3 -> 16 -> 4) also stays exact fp32: its outputs (loc, log sigma) are divided
         // by sigma ~ 1e-2 for peaked materials, so an fp16-split evaluation (measured) raised the p99
@@ -503,11 +537,29 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
         f32x4 bz = *reinterpret_cast<const f32x4*>(Lbb1 + lane * 4);
 #pragma unroll
         for (int m = 0; m < NM; ++m) cacc[m] = zero4;
+        if (SPLIT_PRO) {
+            // split3: the lane's 5 encoded values and its raw coordinate ARE the 8 K-values (two zero pads) of one K = 32 B
+            // fragment; the 22 x W conditioning contraction is 3 x NM fp16 MFMAs instead of 6 x NM exact-fp32 ones
+            Frag ph, pl;
+            const float p03[4] = {pe[0], pe[1], pe[2], pe[3]}, p47[4] = {pe[4], yslab, 0.0f, 0.0f};
+            split_pack<true>(p03, ph.p[0], ph.p[1], pl.p[0], pl.p[1]);
+            split_pack<true>(p47, ph.p[2], ph.p[3], pl.p[2], pl.p[3]);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(Lwcs + (m * 64 + lane) * 16);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(Lwcs_lo + (m * 64 + lane) * 16);
+                cacc[m] = mfma16(ah, ph.v, zero4);
+                cacc[m] = mfma16(ah, pl.v, cacc[m]);
+                cacc[m] = mfma16(al, ph.v, cacc[m]);
+            }
+        }
 #pragma unroll
         for (int s = 0; s < PE_SLABS; ++s) {
             const float b = s < PE_BANDS ? pe[s < PE_BANDS ? s : 0] : yslab;
+            if (!SPLIT_PRO) {
 #pragma unroll
-            for (int m = 0; m < NM; ++m) cacc[m] = mfma4(Lwc[(m * PE_SLABS + s) * 64 + lane], b, cacc[m]);
+                for (int m = 0; m < NM; ++m) cacc[m] = mfma4(Lwc[(m * PE_SLABS + s) * 64 + lane], b, cacc[m]);
+            }
             if (s < BASE_PE_BANDS) bz = mfma4(Lbw1[s * 64 + lane], b, bz);
             if (s == PE_BANDS) bz = mfma4(Lbw1[BASE_PE_BANDS * 64 + lane], b, bz);
         }
@@ -536,6 +588,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
         const float cstep = FUSED ? (ph ? -invT : invT) : cstep1;
         float* const out_pdf = (FUSED && ph) ? p.out_pdf2 : p.out_pdf;
         // ---------------- initial state ------------------------------------------------------------
+        if (FUSED && ph) load_dir(p.in_c);
         float x0 = (FUSED && !ph) ? xi0 : xs0, x1 = (FUSED && !ph) ? xi1 : xs1;
         if (op == OP_SAMPLE && p.in_b == nullptr) {  // draw x0 ~ D_base(. | omega_i) in-kernel
             const unsigned long long ctr = p.offset + (unsigned long long)(p.rng_index ? p.rng_index[qi] : qi);
@@ -617,7 +670,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
 #pragma unroll
                 for (int m = 0; m < NM; ++m) {
                     z[m] = mfma4(win[m], bs, cacc[m]);
-                    zt0[m] = zt0c[m];
+                    if (!MIMS) zt0[m] = zt0c[m];
                     if (JAC) zt1[m] = mfma4(win[m], bt, zero4);
                 }
             }
@@ -899,6 +952,10 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
                 float hv[NM][4], gv[NM][4], t0v[NM][4], t1v[NM][4];
                 Frag bh, bl, b0h, b0l, b1h, b1l;
                 f16x8 wAh[NM], wAl[NM], wBh[NM], wBl[NM];  // (W2 / W4 and W3: each set is requested behind the previous layer's MFMAs)
+                // the constant d/dtheta pre-activations of layer 1 (column 0 of W1 in the accumulator layout) come from LDS every
+                // step instead of living in 8 registers across the whole tile (ordinary loads: the compiler waits for them)
+#pragma unroll
+                for (int m = 0; m < NM; ++m) zt0[m] = Lwt0[m * 64 + lane];
                 lds_read_b128_async_at<O_WH>(wAh[0], lb); lds_read_b128_async_at<O_WH + FR>(wAh[1], lb);
                 if (SPLIT) { lds_read_b128_async_at<O_WHL>(wAl[0], lb); lds_read_b128_async_at<O_WHL + FR>(wAl[1], lb); }
                 // -- hidden layer 1 (tangent pre-activations zt0 = W1 e_theta (constant), zt1 = W1 d(input)/d(phi))
@@ -1240,6 +1297,11 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
         }
         if (FUSED && ++ph < nphase) goto next_phase;
     }
+    if (p.clk) {
+        const unsigned long long dc = (unsigned long long)__builtin_readcyclecounter() - clk_c0;
+        const unsigned long long dr = (unsigned long long)__builtin_amdgcn_s_memrealtime() - clk_r0;
+        if ((threadIdx.x & 63) == 0) { atomicAdd(p.clk, dc); atomicAdd(p.clk + 1, dr); }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1276,6 +1338,9 @@ struct bsdfd_ctx {
     long long n_done;      // launches harvested
     double total_ms;
     float last_ms;
+    unsigned long long* d_clk;  // RING x 2 counters (KParams::clk)
+    double total_cycles, total_ticks;  // sums over harvested launches of the waves' lifetimes: shader cycles, wall-clock ticks
+    double wall_khz;            // rate of the wall clock (hipDeviceAttributeWallClockRate)
 };
 
 namespace {
@@ -1351,6 +1416,16 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
     L.bb1 = off; off += 64 * 16;
     L.bw2 = off; off += 64 * 16;
     L.bb2 = off; off += 16;
+    // conditioning weights as fp16 hi / lo A-fragments (split3; SPLIT_PRO in the kernel): K slot (g, j) of lane group g =
+    // encoded value (band j, fn g >> 1, dim g & 1) for j < 5, the raw coordinate y_g for j = 5 and g < 2, else zero.
+    // Appended BEHIND everything else so that the MIM kernels' compile-time fragment offsets do not move.
+    L.wcs = L.wcs_lo = 0;
+    if (prec == BSDFD_PREC_SPLIT3) {
+        L.wcs = off; off += NM * 64 * 16;
+        L.wcs_lo = off; off += NM * 64 * 16;
+    }
+    // column 0 of the (scaled) layer-1 matrix in the MFMA accumulator layout: lane (g, q) holds units 16 m + 4 g + r (MIMS)
+    L.wt0 = off; off += NM * 64 * 16;
     L.total = align16(off);
     std::vector<char> img(L.total, 0);
     auto F = [&](int o) { return reinterpret_cast<float*>(img.data() + o); };
@@ -1377,6 +1452,21 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
         }
     }
     for (int r = 0; r < 4; ++r) F(L.bb2)[r] = d.base_b2[r];
+    for (int m = 0; m < NM; ++m)
+        for (int l = 0; l < 64; ++l)
+            for (int r = 0; r < 4; ++r) F(L.wt0)[(m * 64 + l) * 4 + r] = d.w_in[(16 * m + 4 * (l >> 4) + r) * IN + 0];
+    if (prec == BSDFD_PREC_SPLIT3)
+        for (int m = 0; m < NM; ++m)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int g = l >> 4, unit = 16 * m + (l & 15);
+                    float w = 0.0f;
+                    if (j < PE_BANDS) w = d.w_in[unit * IN + SD + 1 + 2 + 4 * j + 2 * (g >> 1) + (g & 1)];
+                    else if (j == PE_BANDS && g < 2) w = d.w_in[unit * IN + SD + 1 + g];
+                    const float hi = f16_round(w);
+                    H(L.wcs)[((size_t)m * 64 + l) * 8 + j] = f32_to_f16_bits(w);
+                    H(L.wcs_lo)[((size_t)m * 64 + l) * 8 + j] = f32_to_f16_bits(w - hi);
+                }
 
     if (prec == BSDFD_PREC_F32) {
         for (int layer = 0; layer < NH - 1; ++layer)
@@ -1493,8 +1583,13 @@ hipError_t harvest(bsdfd_handle h, int slot) {
     float ms = 0.f;
     e = hipEventElapsedTime(&ms, h->ev0[slot], h->ev1[slot]);
     if (e != hipSuccess) return e;
+    unsigned long long st[2];
+    e = hipMemcpy(st, h->d_clk + (size_t)slot * 2, sizeof st, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return e;
     h->pending[slot] = false;
     h->total_ms += ms;
+    h->total_cycles += (double)st[0];
+    h->total_ticks += (double)st[1];
     h->last_ms = ms;
     h->n_done++;
     return hipSuccess;
@@ -1535,8 +1630,10 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     if (op != OP_SAMPLES_ONLY && !out_pdf) return fail(BSDFD_EINVAL, "null pdf output pointer");
     if (io == IO_PLUGIN_FULLSPHERE && h->domain != BSDFD_DOMAIN_SPHERICAL)
         return fail(BSDFD_EINVAL, "the full-sphere plugin variant needs a spherical-domain handle");
-    if ((ctx.out && op != OP_SAMPLE) || (ctx.in && op != OP_PDF))
-        return fail(BSDFD_EINVAL, "a per-query context is written by sample calls and read by pdf calls only");
+    if ((ctx.out || ctx.in) && op != OP_SAMPLE && op != OP_PDF)
+        return fail(BSDFD_EINVAL, "a per-query context is written / read by the sample and pdf calls only");
+    if (ctx.out && ctx.in)
+        return fail(BSDFD_EINVAL, "a call either writes a per-query context (ctx_out) or reads one (ctx_in), not both");
     if (ctx.rng_index && (op == OP_PDF || op == OP_SAMPLES_ONLY))
         return fail(BSDFD_EINVAL, "rng_index applies to calls that draw base samples (sample, sample_pdf)");
     if ((reinterpret_cast<uintptr_t>(ctx.out) | reinterpret_cast<uintptr_t>(ctx.in)) & 15u)
@@ -1553,6 +1650,7 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     kp.nseg = 0;
     kp.chunk_log2 = 3;
     kp.ctx_out = ctx.out; kp.ctx_in = ctx.in; kp.seg_base = ctx.seg_base; kp.rng_index = ctx.rng_index;
+    kp.clk = nullptr;
 
     const int NM = h->width / 16;
     const int threads = threads_for(NM);
@@ -1621,6 +1719,8 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
         if (h->profiling) {
             slot = (int)(h->n_rec % bsdfd_ctx::RING);
             if (h->pending[slot]) HIP_TRY(harvest(h, slot));
+            kp.clk = h->d_clk + (size_t)slot * 2;
+            HIP_TRY(hipMemsetAsync(kp.clk, 0, 2 * sizeof(unsigned long long), s));
             HIP_TRY(hipEventRecord(h->ev0[slot], s));
         }
     }
@@ -1696,8 +1796,12 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     h->state_dim = d->domain == BSDFD_DOMAIN_DISK ? 2 : 3;
     h->in_dim = h->state_dim + 1 + 2 + 4 * PE_BANDS;
     h->device = dev; h->num_cu = prop.multiProcessorCount;
-    h->profiling = false; h->d_img = nullptr;
-    h->n_rec = h->n_done = 0; h->total_ms = 0.0; h->last_ms = -1.0f;
+    h->profiling = false; h->d_img = nullptr; h->d_clk = nullptr;
+    h->n_rec = h->n_done = 0; h->total_ms = 0.0; h->last_ms = -1.0f; h->total_cycles = h->total_ticks = 0.0;
+    {
+        int khz = 0;
+        h->wall_khz = hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess ? (double)khz : 0.0;
+    }
     for (int i = 0; i < bsdfd_ctx::RING; ++i) { h->pending[i] = false; h->ev0[i] = nullptr; h->ev1[i] = nullptr; }
     std::vector<char> img = build_image(*d, prec, h->L);
     if (h->L.total < 0) {
@@ -1710,6 +1814,7 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_img), img.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_img, img.data(), img.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_clk), (size_t)bsdfd_ctx::RING * 2 * sizeof(unsigned long long));
     for (int i = 0; i < bsdfd_ctx::RING && e == hipSuccess; ++i) {
         e = hipEventCreate(&h->ev0[i]);
         if (e == hipSuccess) e = hipEventCreate(&h->ev1[i]);
@@ -1725,6 +1830,7 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     }
     if (e != hipSuccess) {
         if (h->d_img) (void)hipFree(h->d_img);
+        if (h->d_clk) (void)hipFree(h->d_clk);
         for (int i = 0; i < bsdfd_ctx::RING; ++i) {
             if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
             if (h->ev1[i]) (void)hipEventDestroy(h->ev1[i]);
@@ -1779,6 +1885,7 @@ int bsdfd_create_from_file(const char* path, int32_t precision, bsdfd_handle* ou
 void bsdfd_destroy(bsdfd_handle h) {
     if (!h) return;
     if (h->d_img) (void)hipFree(h->d_img);
+    if (h->d_clk) (void)hipFree(h->d_clk);
     for (int i = 0; i < bsdfd_ctx::RING; ++i) {
         (void)hipEventDestroy(h->ev0[i]);
         (void)hipEventDestroy(h->ev1[i]);
@@ -1842,7 +1949,6 @@ int bsdfd_plugin_sample_ex(bsdfd_handle h, int32_t variant, const float* wi, con
                            void* stream) {
     if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
         return fail(BSDFD_EINVAL, "unknown plugin variant");
-    if (opts && opts->ctx_in) return fail(BSDFD_EINVAL, "sample calls write a per-query context (ctx_out), they do not read one");
     return run(h, OP_SAMPLE, variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, x0, seed, offset,
                N, T, wo, pdf_sa, stream, nullptr, nullptr, nullptr, CtxArg(opts));
 }
@@ -1851,7 +1957,6 @@ int bsdfd_plugin_pdf_ex(bsdfd_handle h, int32_t variant, const float* wi, const 
                         float* pdf_sa, const bsdfd_opts* opts, void* stream) {
     if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
         return fail(BSDFD_EINVAL, "unknown plugin variant");
-    if (opts && opts->ctx_out) return fail(BSDFD_EINVAL, "pdf calls read a per-query context (ctx_in), they do not write one");
     return run(h, OP_PDF, variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, wo, 0, 0, N, T,
                nullptr, pdf_sa, stream, nullptr, nullptr, nullptr, CtxArg(opts));
 }
@@ -1861,7 +1966,6 @@ int bsdfd_plugin_sample_multi_ex(const bsdfd_handle* handles, int32_t n_handles,
                                  float* pdf_sa, const bsdfd_opts* opts, void* stream) {
     if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
         return fail(BSDFD_EINVAL, "unknown plugin variant");
-    if (opts && opts->ctx_in) return fail(BSDFD_EINVAL, "sample calls write a per-query context (ctx_out), they do not read one");
     return run_multi(handles, n_handles, seg_end, OP_SAMPLE,
                      variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, x0, seed, offset, T, wo,
                      pdf_sa, stream, nullptr, nullptr, CtxArg(opts));
@@ -1872,7 +1976,6 @@ int bsdfd_plugin_pdf_multi_ex(const bsdfd_handle* handles, int32_t n_handles, co
                               void* stream) {
     if (variant != BSDFD_PLUGIN_MEASURED && variant != BSDFD_PLUGIN_FULLSPHERE)
         return fail(BSDFD_EINVAL, "unknown plugin variant");
-    if (opts && opts->ctx_out) return fail(BSDFD_EINVAL, "pdf calls read a per-query context (ctx_in), they do not write one");
     return run_multi(handles, n_handles, seg_end, OP_PDF,
                      variant == BSDFD_PLUGIN_MEASURED ? IO_PLUGIN : IO_PLUGIN_FULLSPHERE, wi, wo, 0, 0, T, nullptr,
                      pdf_sa, stream, nullptr, nullptr, CtxArg(opts));
@@ -1938,6 +2041,7 @@ int bsdfd_set_profiling(bsdfd_handle h, int32_t enable) {
     h->profiling = enable != 0;
     h->n_rec = h->n_done = 0;
     h->total_ms = 0.0;
+    h->total_cycles = h->total_ticks = 0.0;
     h->last_ms = -1.0f;
     return BSDFD_OK;
 }
@@ -1955,6 +2059,15 @@ int bsdfd_profile_read(bsdfd_handle h, int64_t* n_launches, double* total_ms) {
     return BSDFD_OK;
 }
 
+int bsdfd_profile_clock_mhz(bsdfd_handle h, double* mhz) {
+    if (!mhz) return fail(BSDFD_EINVAL, "null argument");
+    int rc = bsdfd_profile_read(h, nullptr, nullptr);
+    if (rc != BSDFD_OK) return rc;
+    std::lock_guard<std::mutex> lock(h->prof_mu);
+    *mhz = (h->total_ticks > 0.0 && h->wall_khz > 0.0) ? h->total_cycles / h->total_ticks * h->wall_khz * 1e-3 : 0.0;
+    return BSDFD_OK;
+}
+
 float bsdfd_last_kernel_ms(bsdfd_handle h) {
     if (!h) return -1.0f;
     {
@@ -1967,6 +2080,6 @@ float bsdfd_last_kernel_ms(bsdfd_handle h) {
 }
 
 const char* bsdfd_last_error(void) { return g_err.c_str(); }
-const char* bsdfd_version(void) { return "bsdfd 0.3 (gfx950)"; }
+const char* bsdfd_version(void) { return "bsdfd 0.4 (gfx950; " BSDFD_LDS_VARIANT ")"; }
 
 }  // extern "C"

@@ -213,7 +213,8 @@ void plugin_pdf_out(int64_t h, int64_t variant, const Tensor& wi, const Tensor& 
                         pdf.data_ptr<float>(), L.stream));
 }
 
-// ---- per-query context (bsdfd_context_bytes): sample() writes it, pdf() for the same wi reads it ------
+// ---- per-query context (bsdfd_context_bytes): whichever of sample() / pdf() sees a wi array first writes it, the later
+// calls for the same wi read it (`ctx_read` / `ctx_write` select the direction; the defaults are sample-writes, pdf-reads) ------
 void* ctx_ptr(const Tensor& ctx, int64_t h, int64_t n, const at::Device& dev) {
     const int64_t need = bsdfd_context_bytes(as_handle(h), n, 1);
     TORCH_CHECK(need >= 0, "bsdfd_context_bytes: bad arguments");
@@ -231,7 +232,7 @@ int64_t context_floats(int64_t h, int64_t n, int64_t n_segments) {
 
 void plugin_sample_ex_out(int64_t h, int64_t variant, const Tensor& wi, const std::optional<Tensor>& x0, int64_t seed,
                           int64_t offset, int64_t T, Tensor wo, Tensor pdf, const std::optional<Tensor>& ctx,
-                          const std::optional<Tensor>& rng_index) {
+                          const std::optional<Tensor>& rng_index, bool ctx_read) {
     const at::Device dev = wi.device();
     const float* wip = in2d(wi, 3, "wi", dev);
     const int64_t n = wi.size(0);
@@ -240,7 +241,10 @@ void plugin_sample_ex_out(int64_t h, int64_t variant, const Tensor& wi, const st
     TORCH_CHECK(pdf.device() == dev && pdf.scalar_type() == at::kFloat && pdf.dim() == 1 && pdf.size(0) == n && pdf.is_contiguous(),
                 "pdf (out) must be a contiguous float32 tensor of shape [", n, "] on ", dev);
     bsdfd_opts o{};
-    if (ctx.has_value()) o.ctx_out = ctx_ptr(*ctx, h, n, dev);
+    if (ctx.has_value()) {
+        if (ctx_read) o.ctx_in = ctx_ptr(*ctx, h, n, dev);
+        else o.ctx_out = ctx_ptr(*ctx, h, n, dev);
+    }
     if (rng_index.has_value()) {
         const Tensor& r = *rng_index;
         TORCH_CHECK(r.device() == dev && r.scalar_type() == at::kLong && r.dim() == 1 && r.size(0) == n && r.is_contiguous(),
@@ -253,7 +257,8 @@ void plugin_sample_ex_out(int64_t h, int64_t variant, const Tensor& wi, const st
                               pdf.data_ptr<float>(), &o, L.stream));
 }
 
-void plugin_pdf_ex_out(int64_t h, int64_t variant, const Tensor& wi, const Tensor& wo, int64_t T, Tensor pdf, const Tensor& ctx) {
+void plugin_pdf_ex_out(int64_t h, int64_t variant, const Tensor& wi, const Tensor& wo, int64_t T, Tensor pdf, Tensor ctx,
+                       bool ctx_write) {
     const at::Device dev = wi.device();
     const float* wip = in2d(wi, 3, "wi", dev);
     const int64_t n = wi.size(0);
@@ -261,7 +266,8 @@ void plugin_pdf_ex_out(int64_t h, int64_t variant, const Tensor& wi, const Tenso
     TORCH_CHECK(pdf.device() == dev && pdf.scalar_type() == at::kFloat && pdf.dim() == 1 && pdf.size(0) == n && pdf.is_contiguous(),
                 "pdf (out) must be a contiguous float32 tensor of shape [", n, "] on ", dev);
     bsdfd_opts o{};
-    o.ctx_in = ctx_ptr(ctx, h, n, dev);
+    if (ctx_write) o.ctx_out = ctx_ptr(ctx, h, n, dev);
+    else o.ctx_in = ctx_ptr(ctx, h, n, dev);
     Launch L(dev);
     ok(bsdfd_plugin_pdf_ex(as_handle(h), static_cast<int32_t>(variant), wip, wop, n, static_cast<int32_t>(T),
                            pdf.data_ptr<float>(), &o, L.stream));
@@ -287,6 +293,7 @@ TORCH_LIBRARY(bsdfd, m) {
     m.def("plugin_pdf_out(int handle, int variant, Tensor wi, Tensor wo, int T, Tensor(a!) pdf) -> ()", &plugin_pdf_out);
     m.def("context_floats(int handle, int n, int n_segments) -> int", &context_floats);
     m.def("plugin_sample_ex_out(int handle, int variant, Tensor wi, Tensor? x0, int seed, int offset, int T, Tensor(a!) wo, "
-          "Tensor(b!) pdf, Tensor(c!)? ctx, Tensor? rng_index) -> ()", &plugin_sample_ex_out);
-    m.def("plugin_pdf_ex_out(int handle, int variant, Tensor wi, Tensor wo, int T, Tensor(a!) pdf, Tensor ctx) -> ()", &plugin_pdf_ex_out);
+          "Tensor(b!) pdf, Tensor(c!)? ctx, Tensor? rng_index, bool ctx_read=False) -> ()", &plugin_sample_ex_out);
+    m.def("plugin_pdf_ex_out(int handle, int variant, Tensor wi, Tensor wo, int T, Tensor(a!) pdf, Tensor(b!) ctx, bool ctx_write=False) -> ()",
+          &plugin_pdf_ex_out);
 }

@@ -72,10 +72,12 @@ class MaterialTable:
         return groups
 
     def _multi(self, which, members, seg_end_all, T, variant, wi_s, aux_s, seed, offset, out_wo, out_pdf, ctx=None,
-               gkey=None, rng_rows=None):
+               gkey=None, rng_rows=None, ctx_fill=None):
         """``ctx`` (a dict, or None): per-query contexts (include/bsdfd.h, bsdfd_context_bytes) of the runs of this
-        wavefront — a "sample" call creates and fills one buffer per (kernel signature, run), a "pdf" call on the same
-        bucketed ``wi`` reads them instead of recomputing the per-query prologue.
+        wavefront — the FILLING call (``ctx_fill``; default: "sample" fills, "pdf" reads) writes one buffer per (kernel
+        signature, run), the other call on the same bucketed ``wi`` reads them instead of recomputing the per-query prologue.
+        The dict keeps ONE buffer per (kernel signature, run number), grown to the largest wavefront seen, together with the
+        bucket layout it was last filled for; a reading call whose layout differs is refused.
 
         Segmented launch(es) for the materials `members` of one kernel signature.  The bucketed arrays
         are ordered by material id, so a group's buckets may be interleaved with other groups'; each
@@ -86,8 +88,10 @@ class MaterialTable:
         stream = C.c_void_p(torch.cuda.current_stream(wi_s.device).cuda_stream)
         # the C ABI takes cumulative ends; non-adjacent buckets are issued as separate runs
         run_h, run_end, base = [], [], None
+        run_no = 0
+        fill = (which == "sample") if ctx_fill is None else bool(ctx_fill)
         def flush():
-            nonlocal run_h, run_end, base
+            nonlocal run_h, run_end, base, run_no
             if not run_h:
                 return 0
             k = len(run_h)
@@ -97,27 +101,30 @@ class MaterialTable:
             wi_p = C.c_void_p(wi_s.data_ptr() + off_rows * 12)
             cbuf = None
             if ctx is not None and which in ("sample", "pdf"):
-                ckey = (gkey, base, tuple(run_end))
-                if which == "sample":
+                ckey, layout = (gkey, run_no), (base, tuple(run_end))
+                run_no += 1
+                ent = ctx.get(ckey)
+                if fill:
                     nbytes = int(L.bsdfd_context_bytes(run_h[0], run_end[-1] - base, k))
-                    cbuf = ctx.get(ckey)
-                    if cbuf is None or cbuf.numel() * 4 < nbytes or cbuf.device != wi_s.device:
-                        cbuf = ctx[ckey] = torch.empty((nbytes // 4,), dtype=torch.float32, device=wi_s.device)
-                else:
-                    cbuf = ctx.get(ckey)
-                    if cbuf is None:
-                        raise ValueError("pdf(ctx=...) needs the context a sample(ctx=...) call of the SAME bucketed "
-                                         "wavefront filled")
+                    if ent is None or ent["buf"].numel() * 4 < nbytes or ent["buf"].device != wi_s.device:
+                        ent = ctx[ckey] = {"buf": torch.empty((nbytes // 4,), dtype=torch.float32, device=wi_s.device)}
+                    ent["layout"] = layout
+                elif ent is None or ent.get("layout") != layout:
+                    raise ValueError("a context-reading call needs the context a filling call of the SAME bucketed wavefront "
+                                     "(same plan, same wi array) wrote: sample(ctx=) before pdf(ctx=), or pdf(ctx=, "
+                                     "ctx_fill=True) before sample(ctx=, ctx_fill=False)")
+                cbuf = ent["buf"]
+            c_out, c_in = (cbuf, None) if fill else (None, cbuf)
             if which == "sample" and (cbuf is not None or rng_rows is not None):
                 x0_p = None if aux_s is None else C.c_void_p(aux_s.data_ptr() + off_rows * 8)
                 # rng_rows: counter of a row = offset + its ORIGINAL lane index (not its bucketed position)
-                o = _lib.opts(ctx_out=cbuf, rng_index=rng_rows, byte_offset_rng=off_rows * 8)
+                o = _lib.opts(ctx_out=c_out, ctx_in=c_in, rng_index=rng_rows, byte_offset_rng=off_rows * 8)
                 r = L.bsdfd_plugin_sample_multi_ex(arr_h, k, arr_e, variant, wi_p, x0_p, seed,
                                                    offset if rng_rows is not None else offset + off_rows, T,
                                                    C.c_void_p(out_wo.data_ptr() + off_rows * 12),
                                                    C.c_void_p(out_pdf.data_ptr() + off_rows * 4), C.byref(o), stream)
             elif which == "pdf" and cbuf is not None:
-                o = _lib.opts(ctx_in=cbuf)
+                o = _lib.opts(ctx_out=c_out, ctx_in=c_in)
                 r = L.bsdfd_plugin_pdf_multi_ex(arr_h, k, arr_e, variant, wi_p,
                                                 C.c_void_p(aux_s.data_ptr() + off_rows * 12), T,
                                                 C.c_void_p(out_pdf.data_ptr() + off_rows * 4), C.byref(o), stream)
@@ -246,18 +253,21 @@ class MaterialTable:
 
     def sample(self, material_id: torch.Tensor, wi: torch.Tensor, seed: int = 0, offset: int = 0,
                T: Optional[int] = None, x0: Optional[torch.Tensor] = None, segmented: bool = True,
-               bucketed: bool = False, ctx: Optional[dict] = None, rng: str = "lane"):
+               bucketed: bool = False, ctx: Optional[dict] = None, rng: str = "lane", ctx_fill: bool = True):
         """wi [N,3], material_id [N] -> (wo [N,3], pdf_sa [N]) in the callers' order.
         ``rng``: ``"lane"`` (default) — the Philox counter of a query is ``offset + its ORIGINAL lane index``, so the base
         draws depend on neither the bucketing nor how the wavefront is sharded over calls / GPUs (a shard passes its
         first lane's global index as ``offset``); ``"bucketed"`` — ``offset + row in the bucketed
         array`` (what a caller that keeps no lane order would use).
         ``ctx``: a dict this call fills with the wavefront's per-query contexts; hand the same dict (and the same
-        plan and ``wi``) to ``pdf(..., ctx=)`` and it skips the per-query prologue (identical results).
+        plan and ``wi``) to ``pdf(..., ctx=)`` and it skips the per-query prologue (identical results).  The other order
+        works too: ``pdf(..., ctx=d, ctx_fill=True)`` first, then ``sample(..., ctx=d, ctx_fill=False)``.  Segmented path only.
         Identical for the segmented and the per-bucket path.  ``bucketed=True``: ``material_id`` is a
         plan, ``wi`` / ``x0`` are already in bucket order (``gather(plan, wi)``) and the results stay in it."""
         wi = self._chk_in(wi, 3, "wi")
         x0 = self._chk_in(x0, 2, "x0", wi.shape[0])
+        if ctx is not None and not segmented:
+            raise ValueError("ctx= is a feature of the segmented path (segmented=False issues one plain call per bucket)")
         if bucketed:
             rows, counts, seg_end = self._plan_bucketed(material_id)
             if wi.shape[0] != rows.shape[0]:
@@ -276,7 +286,7 @@ class MaterialTable:
             with torch.cuda.device(wi.device):
                 for (dom, w, nh, prec, Tm, var), members in self._groups().items():
                     self._multi("sample", members, seg_end, Tm if T is None else T, var, wi_s, x0_s, seed, offset,
-                                wo_s, pdf_s, ctx=ctx, gkey=(dom, w, nh, prec, var), rng_rows=rng_rows)
+                                wo_s, pdf_s, ctx=ctx, gkey=(dom, w, nh, prec, var), rng_rows=rng_rows, ctx_fill=ctx_fill)
         else:
             lo = 0
             for m, n in enumerate(counts):
@@ -331,9 +341,11 @@ class MaterialTable:
         return wo, po, pl
 
     def pdf(self, material_id: torch.Tensor, wi: torch.Tensor, wo: torch.Tensor, T: Optional[int] = None,
-            segmented: bool = True, bucketed: bool = False, ctx: Optional[dict] = None):
+            segmented: bool = True, bucketed: bool = False, ctx: Optional[dict] = None, ctx_fill: bool = False):
         wi = self._chk_in(wi, 3, "wi")
         wo = self._chk_in(wo, 3, "wo", wi.shape[0])
+        if ctx is not None and not segmented:
+            raise ValueError("ctx= is a feature of the segmented path (segmented=False issues one plain call per bucket)")
         if bucketed:
             rows, counts, seg_end = self._plan_bucketed(material_id)
             if wi.shape[0] != rows.shape[0]:
@@ -347,7 +359,7 @@ class MaterialTable:
             with torch.cuda.device(wi.device):
                 for (dom, w, nh, prec, Tm, var), members in self._groups().items():
                     self._multi("pdf", members, seg_end, Tm if T is None else T, var, wi_s, wo_s, 0, 0, None, pdf_s,
-                                ctx=ctx, gkey=(dom, w, nh, prec, var))
+                                ctx=ctx, gkey=(dom, w, nh, prec, var), ctx_fill=ctx_fill)
         else:
             lo = 0
             for m, n in enumerate(counts):

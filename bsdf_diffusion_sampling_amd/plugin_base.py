@@ -89,12 +89,25 @@ class NeuralBSDFCore:
         self.albedo = torch.tensor(get("albedo", [1.0, 1.0, 1.0]), dtype=torch.float32)
         fw = self._load_weights(get("weights", None), get("checkpoint_dir", None))
         self.sampler = FlowSampler(fw, precision=self.precision)
-        # per-query context of the last sample() call (include/bsdfd.h, bsdfd_context_bytes): a renderer calls
-        # sample(si) and then pdf(si, wl) for the same intersections (rendering/brdf_measured_disk.py:59,112), so pdf()
-        # may skip what depends on si.wi alone.  Keyed on the identity of the wi tensor; 144 B per query, capped.
+        # per-query context (include/bsdfd.h, bsdfd_context_bytes): a renderer asks pdf(si, wl) and sample(si) for the same
+        # intersections (rendering/brdf_measured_disk.py:112,59; Mitsuba's path integrator in the order eval_pdf() -> sample()),
+        # so whichever call sees an si.wi first also writes what depends on wi alone and the later ones read it.  Keyed on the
+        # identity + version of the wi tensor and on the sampler handle; 144 B per query (ONE reused buffer per plugin
+        # instance).  Capped at 192 MiB by default: the record pays while it round-trips through the 256 MiB Infinity Cache
+        # (1 Mi queries: -2.4 % of a sample()+pdf() pair) and stops paying once it streams through HBM (16 Mi spherical
+        # queries, 2.4 GB: -1 %), so larger wavefronts run without it.
         self.context_cache = bool(get("context_cache", True))
-        self.context_cache_max_bytes = int(get("context_cache_max_bytes", 4 << 30))
-        self._ctx = None      # (data_ptr, _version, n, device, buffer)
+        self.context_cache_max_bytes = int(get("context_cache_max_bytes", 192 << 20))
+        self._ctx = None        # (key, wi tensor, buffer) of the last launch that FILLED the buffer successfully
+        self._ctx_buf = None
+        self._ctx_event = None  # recorded behind every launch that touched the buffer (cross-stream ordering)
+        self._ctx_stream = None
+        # a host that hands every call a fresh copy of wi (e.g. a separate `si.wi.torch()` per method) never hits: after
+        # `context_cache_patience` fills in a row that nobody read, filling stops (it costs ~1 % of a launch) and is retried
+        # once every 64 calls
+        self.context_cache_patience = int(get("context_cache_patience", 4))
+        self._ctx_unread_fills = 0
+        self._ctx_skipped = 0
 
     # -- weight discovery ------------------------------------------------
     def _material_name(self) -> str:
@@ -128,38 +141,71 @@ class NeuralBSDFCore:
         the firefly rule is separate (``apply_firefly_clamp``) because it needs eval()."""
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
-        return self.sampler.plugin_sample(wi, x0, T=self.T, variant=self.VARIANT, seed=seed, offset=offset,
-                                          ctx_out=self._ctx_for_sample(wi))
+        cin, cout, key = self._ctx_lookup(wi)
+        res = self.sampler.plugin_sample(wi, x0, T=self.T, variant=self.VARIANT, seed=seed, offset=offset, ctx_out=cout, ctx_in=cin)
+        self._ctx_done(wi, key, cin, cout)
+        return res
 
     def pdf_t(self, wi: torch.Tensor, wo: torch.Tensor) -> torch.Tensor:
-        return self.sampler.plugin_pdf(wi, wo, T=self.T, variant=self.VARIANT, ctx_in=self._ctx_for_pdf(wi))
+        cin, cout, key = self._ctx_lookup(wi)
+        res = self.sampler.plugin_pdf(wi, wo, T=self.T, variant=self.VARIANT, ctx_in=cin, ctx_out=cout)
+        self._ctx_done(wi, key, cin, cout)
+        return res
 
     # -- context cache -----------------------------------------------------
-    @staticmethod
-    def _wi_key(wi: torch.Tensor):
-        return (wi.data_ptr(), wi._version, wi.shape[0], wi.device)
+    def _wi_key(self, wi: torch.Tensor):
+        return (wi.data_ptr(), wi._version, wi.shape[0], wi.device, id(self.sampler), getattr(self.sampler, "_hi", None))
 
-    def _ctx_for_sample(self, wi):
-        """Buffer the sample launch fills for ``wi`` (None when the cache is off or the wavefront is over the cap)."""
-        self._ctx = None
-        if not self.context_cache or not isinstance(wi, torch.Tensor) or wi.dim() != 2 or wi.shape[0] == 0:
-            return None
-        n = wi.shape[0]
-        need = self.sampler.context_floats(n)
+    def _ctx_lookup(self, wi):
+        """(ctx_in, ctx_out, key) for a launch on ``wi``: a hit reads the buffer the last filling launch wrote for this very
+        tensor (any of sample_t / pdf_t, in any order); a miss hands out the buffer to fill — it becomes the cached context
+        only once the launch has returned without raising (``_ctx_done``).  (None, None, None): cache off, not a device
+        tensor, or the wavefront is over the cap."""
+        if not self.context_cache or not isinstance(wi, torch.Tensor) or wi.dim() != 2 or wi.shape[0] == 0 or not wi.is_cuda:
+            return None, None, None
+        key = self._wi_key(wi)
+        cur = torch.cuda.current_stream(wi.device)
+        c = self._ctx
+        if c is not None and c[0] == key:
+            self._ctx_order(cur)       # the filling launch may have run on another stream
+            self._ctx_unread_fills = 0
+            return c[2], None, key
+        if self._ctx_unread_fills >= self.context_cache_patience:
+            self._ctx_skipped += 1
+            if self._ctx_skipped % 64:
+                self._ctx = None
+                return None, None, None
+        need = self.sampler.context_floats(wi.shape[0])
         if need * 4 > self.context_cache_max_bytes:
-            return None
-        buf = getattr(self, "_ctx_buf", None)
+            self._ctx = None
+            return None, None, None
+        buf = self._ctx_buf
         if buf is None or buf.numel() < need or buf.device != wi.device:
             buf = self._ctx_buf = torch.empty((need,), dtype=torch.float32, device=wi.device)
-        # the key also pins the tensor object: a freed-and-reallocated wi with the same address cannot alias it
-        self._ctx = (self._wi_key(wi), wi, buf)
-        return buf
+            self._ctx_event = None
+        # about to be overwritten: whatever launch — on whatever stream — still reads the previous contents goes first, and
+        # the old entry is dropped NOW (if this launch raises, the buffer holds neither the old nor the new context)
+        self._ctx = None
+        self._ctx_order(cur)
+        return None, buf, key
 
-    def _ctx_for_pdf(self, wi):
-        c = self._ctx
-        if c is None or not isinstance(wi, torch.Tensor) or self._wi_key(wi) != c[0]:
-            return None
-        return c[2]
+    def _ctx_order(self, cur):
+        if self._ctx_event is not None and self._ctx_stream != cur:
+            cur.wait_event(self._ctx_event)
+
+    def _ctx_done(self, wi, key, cin, cout):
+        """Behind a launch that used the buffer: commit a fill (the key also pins the tensor object: a freed-and-reallocated
+        wi with the same address cannot alias it) and record the event later launches on other streams order against."""
+        if cin is None and cout is None:
+            return
+        if cout is not None:
+            self._ctx = (key, wi, cout)
+            self._ctx_unread_fills += 1
+        cur = torch.cuda.current_stream(wi.device)
+        if self._ctx_event is None:
+            self._ctx_event = torch.cuda.Event()
+        self._ctx_event.record(cur)
+        self._ctx_stream = cur
 
     def invalidate_context(self):
         """Drop the cached context.  The cache trusts torch's version counter: code that rewrites the ``wi`` storage

@@ -160,6 +160,13 @@ class FlowSampler:
         _lib.check(self._L.bsdfd_profile_read(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def profile_clock_mhz(self) -> float:
+        """Shader clock (MHz) the chip sustained under THIS handle's launches since ``set_profiling(True)``: the waves' own
+        shader-cycle / wall-clock counters (bsdfd_profile_clock_mhz); 0 if none were recorded."""
+        mhz = C.c_double()
+        _lib.check(self._L.bsdfd_profile_clock_mhz(self._h, C.byref(mhz)))
+        return mhz.value
+
     def last_kernel_ms(self) -> float:
         return float(self._L.bsdfd_last_kernel_ms(self._h))
 
@@ -208,13 +215,19 @@ class FlowSampler:
     # ---- plugin level (tensor core of MyBSDF.sample / MyBSDF.pdf) ----
     def plugin_sample(self, wi, x0=None, T: int = 4, variant: int = _lib.PLUGIN_MEASURED, seed: int = 0,
                       offset: int = 0, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                      ctx_out: Optional[torch.Tensor] = None, rng_index: Optional[torch.Tensor] = None):
-        """``ctx_out`` (``new_context(N)``): also write the per-query context a following ``plugin_pdf(wi, .,
-        ctx_in=ctx_out)`` for the SAME ``wi`` reads instead of recomputing the prologue (identical results).
+                      ctx_out: Optional[torch.Tensor] = None, rng_index: Optional[torch.Tensor] = None,
+                      ctx_in: Optional[torch.Tensor] = None):
+        """``ctx_out`` (``new_context(N)``): also write the per-query context a later ``plugin_pdf(wi, ., ctx_in=)`` /
+        ``plugin_sample(wi, ctx_in=)`` for the SAME ``wi`` reads instead of recomputing the prologue (identical results);
+        ``ctx_in``: read the context an earlier call (``plugin_pdf(..., ctx_out=)`` or ``plugin_sample(..., ctx_out=)``) wrote
+        for this very ``wi``.  At most one of the two.
         ``rng_index`` (int64 [N]): the Philox counter of row i is ``offset + rng_index[i]`` instead of ``offset + i``
         (a bucketed wavefront passes the rows' original lane indices: draws independent of the bucketing)."""
-        if ctx_out is not None or rng_index is not None:
-            return self._plugin_sample_ex(wi, x0, T, variant, seed, offset, out, ctx_out, rng_index)
+        if ctx_out is not None and ctx_in is not None:
+            raise RuntimeError("a call either writes a per-query context (ctx_out) or reads one (ctx_in), not both")
+        if ctx_out is not None or ctx_in is not None or rng_index is not None:
+            return self._plugin_sample_ex(wi, x0, T, variant, seed, offset, out, ctx_out if ctx_in is None else ctx_in, rng_index,
+                                          ctx_read=ctx_in is not None)
         if self._ops is not None:
             self._dev_chk(wi, "wi")
             if out is None:
@@ -242,7 +255,7 @@ class FlowSampler:
             raise RuntimeError(f"rng_index must be a contiguous int64 tensor of shape [{n}] on {self.device}")
         return idx
 
-    def _plugin_sample_ex(self, wi, x0, T, variant, seed, offset, out, ctx, rng_index):
+    def _plugin_sample_ex(self, wi, x0, T, variant, seed, offset, out, ctx, rng_index, ctx_read=False):
         if self._ops is not None:
             self._dev_chk(wi, "wi")
             if ctx is not None:
@@ -251,7 +264,8 @@ class FlowSampler:
             if out is None:
                 out = (torch.empty((wi.shape[0], 3), dtype=torch.float32, device=self.device),
                        torch.empty((wi.shape[0],), dtype=torch.float32, device=self.device))
-            self._ops.plugin_sample_ex_out(self._hi, variant, wi, x0, _i64(seed), _i64(offset), T, out[0], out[1], ctx, rng_index)
+            self._ops.plugin_sample_ex_out(self._hi, variant, wi, x0, _i64(seed), _i64(offset), T, out[0], out[1], ctx, rng_index,
+                                           ctx_read)
             return out[0], out[1]
         wi = self._chk(wi, 3, "wi")
         n = wi.shape[0]
@@ -264,7 +278,7 @@ class FlowSampler:
             pdf = torch.empty((n,), dtype=torch.float32, device=self.device)
         else:
             wo, pdf = self._chk(out[0], 3, "out wo", n), self._chk1(out[1], n, "out pdf")
-        o = _lib.opts(ctx_out=ctx, rng_index=rng_index)
+        o = _lib.opts(ctx_in=ctx, rng_index=rng_index) if ctx_read else _lib.opts(ctx_out=ctx, rng_index=rng_index)
         with torch.cuda.device(self.device):
             _lib.check(self._L.bsdfd_plugin_sample_ex(self._h, variant, _ptr(wi), _ptr(x0), seed, offset, n, T,
                                                       _ptr(wo), _ptr(pdf), C.byref(o), self._stream()))
@@ -294,22 +308,28 @@ class FlowSampler:
         return wo, pdf_o, pdf_l
 
     def plugin_pdf(self, wi, wo, T: int = 4, variant: int = _lib.PLUGIN_MEASURED,
-                   out: Optional[torch.Tensor] = None, ctx_in: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """``ctx_in``: the context ``plugin_sample(wi, ..., ctx_out=)`` wrote for this very ``wi`` array."""
-        if ctx_in is not None:
+                   out: Optional[torch.Tensor] = None, ctx_in: Optional[torch.Tensor] = None,
+                   ctx_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``ctx_in``: the context an earlier ``plugin_sample`` / ``plugin_pdf`` call wrote (``ctx_out=``) for this very ``wi``
+        array; ``ctx_out`` (``new_context(N)``): write it here (the call order of Mitsuba's path integrator: eval_pdf() for the
+        emitter sample first, sample() second — rendering/brdf_measured_disk.py:126,59).  At most one of the two."""
+        if ctx_out is not None and ctx_in is not None:
+            raise RuntimeError("a call either writes a per-query context (ctx_out) or reads one (ctx_in), not both")
+        if ctx_in is not None or ctx_out is not None:
+            ctx, write = (ctx_in, False) if ctx_out is None else (ctx_out, True)
             if self._ops is not None:
                 self._dev_chk(wi, "wi")
-                self._chk_ctx(ctx_in, wi.shape[0])
+                self._chk_ctx(ctx, wi.shape[0])
                 if out is None:
                     out = torch.empty((wi.shape[0],), dtype=torch.float32, device=self.device)
-                self._ops.plugin_pdf_ex_out(self._hi, variant, wi, wo, T, out, ctx_in)
+                self._ops.plugin_pdf_ex_out(self._hi, variant, wi, wo, T, out, ctx, write)
                 return out
             wi = self._chk(wi, 3, "wi")
             n = wi.shape[0]
             wo = self._chk(wo, 3, "wo", n)
-            self._chk_ctx(ctx_in, n)
+            self._chk_ctx(ctx, n)
             pdf = torch.empty((n,), dtype=torch.float32, device=self.device) if out is None else self._chk1(out, n, "out pdf")
-            o = _lib.opts(ctx_in=ctx_in)
+            o = _lib.opts(ctx_out=ctx) if write else _lib.opts(ctx_in=ctx)
             with torch.cuda.device(self.device):
                 _lib.check(self._L.bsdfd_plugin_pdf_ex(self._h, variant, _ptr(wi), _ptr(wo), n, T, _ptr(pdf),
                                                        C.byref(o), self._stream()))

@@ -133,9 +133,11 @@ int bsdfd_plugin_sample_pdf(bsdfd_handle h, int32_t variant, const float* wi, co
  * (W1[:, PE(omega_i)] PE(omega_i), once per query instead of once per Euler step as rendering/utils/model.py:494
  * recomputes it) and the base-density net's four outputs (evaluated twice per sample() by
  * rendering/utils/mlp_brdf_sampling.py:20,24) — 144 B per query for the 32-wide nets, 272 B for 64-wide.
- * A renderer calls sample(si) and then pdf(si, wl) for the SAME intersections (rendering/brdf_measured_disk.py:59,112
- * are both driven by one `si`): bsdfd_plugin_sample_ex writes the context while it samples (opts->ctx_out),
- * bsdfd_plugin_pdf_ex reads it (opts->ctx_in) instead of re-evaluating the prologue (cart_to_spher(wi), 22 sin/cos, 20 fp32 MFMAs per 16 queries).
+ * A renderer calls sample(si) and pdf(si, wl) for the SAME intersections (rendering/brdf_measured_disk.py:59,112 are
+ * both driven by one `si`) — Mitsuba's path integrator in the order eval_pdf() (emitter sampling, :126 -> :112) first,
+ * sample() (:59) second — so EITHER call may write the context while it runs (opts->ctx_out) and either may read it
+ * (opts->ctx_in) instead of re-evaluating the prologue (cart_to_spher(wi), 22 sin/cos, the conditioning contraction and the
+ * base net: 20 fp32 MFMAs per 16 queries).  A call takes at most one of the two.
  * Results are BIT-IDENTICAL to the calls without a context.  The buffer is opaque device memory of
  * bsdfd_context_bytes(h, N, n_segments) bytes (n_segments = 1 for single-material calls, = n_handles for *_multi
  * calls), 16-byte aligned, valid only for the handle(s), the wi array and — for *_multi — the seg_end layout it
@@ -144,8 +146,8 @@ int64_t bsdfd_context_bytes(bsdfd_handle h, int64_t N, int32_t n_segments);
 
 /* Optional arguments of the plugin-level calls (NULL pointer / all-zero struct = the plain call). */
 typedef struct bsdfd_opts {
-    void* ctx_out;             /* sample calls: write the per-query context here                                   */
-    const void* ctx_in;        /* pdf calls: read the context a sample call wrote for the same wi array             */
+    void* ctx_out;             /* sample / pdf calls: also write the per-query context of this wi array here        */
+    const void* ctx_in;        /* sample / pdf calls: read the context an earlier call wrote for the same wi array  */
     const int64_t* rng_index;  /* sample calls: device array [N]; the Philox counter of row i is offset +
                                 * rng_index[i] instead of offset + i.  A wavefront that was bucketed by material
                                 * passes the rows' ORIGINAL lane indices here: the base draws then depend on neither
@@ -205,6 +207,14 @@ int bsdfd_flow_samples_only(bsdfd_handle h, const float* omega_i, const float* x
 int bsdfd_set_profiling(bsdfd_handle h, int32_t enable);
 int bsdfd_profile_read(bsdfd_handle h, int64_t* n_launches, double* total_ms);
 float bsdfd_last_kernel_ms(bsdfd_handle h);
+/* Shader clock (MHz) the chip sustained UNDER THE PROFILED LAUNCHES THEMSELVES: while profiling is enabled every wave adds its
+ * lifetime in shader cycles (s_memtime) and in ticks of the constant-rate wall clock (s_memrealtime,
+ * hipDeviceAttributeWallClockRate) to two words of the handle — both read by the same wave, so counter offsets between CUs
+ * cancel; the ratio of the sums x the wall-clock rate is the clock, averaged over the waves' lifetimes.  This is what
+ * bench.py's issue-bound entry divides by (the stand-alone probe below runs a similar instruction mix, not the kernel itself,
+ * and may draw a different clock: "DVFS give-back", MI355X_MICROARCH.md).  0 if nothing was recorded.  No counterpart in the
+ * reference. */
+int bsdfd_profile_clock_mhz(bsdfd_handle h, double* mhz);
 
 /* Shader clock (MHz) the chip sustains under the flow kernel's instruction mix: a ~6 ms probe launch on every
  * CU, shader-cycle count of the LONGEST-lived wave (maximum over all waves) / HIP-event duration (csrc/clock.hip).

@@ -56,7 +56,9 @@ def _built_library():
 def same_density(a, b, p99=1e-4, outliers=1e-3):
     """Two fp32 evaluation orders of the same density (e.g. the fused sample+pdf kernel, which carries the Jacobian in forward
     mode, against the single-op kernels, which form it by meeting in the middle): equal up to fp32 noise — p99 of the relative
-    difference <= 1e-4 over the resolved rows, at most 0.1 % of the rows beyond 1e-3 (near-singular steps), zeros in the same rows."""
+    difference <= 1e-4 over the resolved rows, at most 0.1 % of the rows beyond 1e-3 (near-singular steps) and none beyond 5 %
+    (a wrong determinant on rare rows — a bad lane of the cross-lane reduction, a partial tile — would be off by O(1)), zeros in
+    the same rows."""
     import numpy as np
     import torch
     a = a.detach().cpu().numpy().astype(np.float64) if isinstance(a, torch.Tensor) else np.asarray(a, np.float64)
@@ -69,4 +71,5 @@ def same_density(a, b, p99=1e-4, outliers=1e-3):
     if not ok.any():
         return bool(np.allclose(a, b, atol=1e-12))
     rel = np.abs(a - b)[ok] / np.abs(b[ok])
-    return bool(np.percentile(rel, 99) <= p99 and (rel > 1e-3).mean() <= outliers and ((a == 0) == (b == 0))[ok].all())
+    return bool(np.percentile(rel, 99) <= p99 and (rel > 1e-3).mean() <= outliers and rel.max() <= 5e-2
+                and ((a == 0) == (b == 0))[ok].all())

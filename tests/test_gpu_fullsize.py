@@ -146,6 +146,21 @@ def test_mixed_material_table_matches_per_material_calls():
     assert torch.equal(tab.pdf(plan, wi, wl, ctx=cx), tab.pdf(plan, wi, wl))
     with pytest.raises(ValueError, match="context"):
         tab.pdf(plan, wi, wl, ctx={})
+    # the other order (a path tracer asks pdf for the emitter sample first): pdf fills, sample reads
+    cy = {}
+    assert torch.equal(tab.pdf(plan, wi, wl, ctx=cy, ctx_fill=True), tab.pdf(plan, wi, wl))
+    e = tab.sample(plan, wi, seed=11, offset=5, ctx=cy, ctx_fill=False)
+    assert torch.equal(a[0], e[0]) and torch.equal(a[1], e[1])
+    # the dict keeps one buffer per (kernel signature, run): wavefronts with other bucket sizes reuse it, a reader with another
+    # layout than the last fill is refused, and the per-bucket path refuses ctx= instead of ignoring it
+    ids_b = torch.randint(0, len(tab), (n // 2,), generator=torch.Generator().manual_seed(44)).to(_dev())
+    for k in range(3):
+        tab.sample(ids_b if k % 2 else ids, wi[: n // 2] if k % 2 else wi, seed=11, ctx=cx)
+    assert len(cx) == 1
+    with pytest.raises(ValueError, match="context"):
+        tab.pdf(ids_b, wi[: n // 2], wl[: n // 2], ctx=cx)       # cx was last filled for the full wavefront
+    with pytest.raises(ValueError, match="segmented"):
+        tab.sample(ids, wi, seed=11, ctx={}, segmented=False)
     # an id with no queries is fine; so is a single-row bucket
     ids2 = torch.zeros(1000, dtype=torch.int64, device=_dev())
     ids2[7] = 2

@@ -346,7 +346,78 @@ def test_asynchronous_lds_reads_are_not_touched_before_their_wait():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_mix.py"), "--check-async"], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count(", 0 violations") == 6 and "25 asynchronous" in r.stdout and "21 asynchronous" in r.stdout
+    assert r.stdout.count(", 0 violations") == 8 and "25 asynchronous" in r.stdout and "21 asynchronous" in r.stdout
+
+
+_ASM_OK = """
+_ZN12_GLOBAL__N_111flow_kernelILi0ELi2ELi2ELb1ELi3ELb0EEEvNS_7KParamsE:
+\ts_load_dword s0, s[4:5], 0x0
+.LBB0_1:
+\t;;#ASMSTART
+\tds_read_b128 v[10:13], v2 offset:512
+\t;;#ASMEND
+\tv_mul_f32_e32 v3, v4, v5
+\tv_mfma_f32_16x16x32_f16 v[20:23], v[30:33], v[34:37], 0
+\t;;#ASMSTART
+\ts_waitcnt lgkmcnt(0)
+\t;;#ASMEND
+\tv_mfma_f32_16x16x32_f16 v[20:23], v[10:13], v[34:37], v[20:23]
+\ts_cbranch_scc1 .LBB0_1
+\ts_endpgm
+"""
+
+
+def test_asmcheck_flags_a_touched_asynchronous_destination(tmp_path):
+    """bsdf_diffusion_sampling_amd/_asmcheck.py on hand-made assembly: clean code passes; a copy out of a pending destination,
+    a spill of one, spill traffic inside the Euler loop, and a branch with reads pending are each reported."""
+    from bsdf_diffusion_sampling_amd import _asmcheck as A
+    key = "flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E"
+    n, bad = A.check_async_lines(_ASM_OK.splitlines(), key)
+    assert n == 1 and bad == []
+    for doctor, what in (("\tv_mov_b32_e32 v50, v11", "touches v11"),                                  # the compiler copies a pending register
+                         ("\tscratch_store_dwordx4 off, v[10:13], off offset:16", "touches v1"),       # ... or spills one
+                         ("\ts_cbranch_vccz .LBB0_1", "control flow")):
+        txt = _ASM_OK.replace("\tv_mul_f32_e32 v3, v4, v5", doctor)
+        n, bad = A.check_async_lines(txt.splitlines(), key)
+        assert n == 1 and bad and what in bad[0], (doctor, bad)
+    txt = _ASM_OK.replace("\ts_cbranch_scc1 .LBB0_1", "\tscratch_load_dword v60, off, off offset:4\n\ts_cbranch_scc1 .LBB0_1")
+    n, bad = A.check_async_lines(txt.splitlines(), key)
+    assert bad and "scratch instructions inside the Euler-step loop" in bad[0]
+    f = tmp_path / "k.s"
+    f.write_text(_ASM_OK)
+    assert A.check_file(str(f)) == {"_ZN12_GLOBAL__N_111flow_kernelILi0ELi2ELi2ELb1ELi3ELb0EEEvNS_7KParamsE": (1, [])}
+
+
+def test_build_falls_back_to_compiler_managed_lds_reads_when_the_asm_check_fails(tmp_path, monkeypatch, capsys):
+    """_lib.build() verifies the assembly of ITS OWN compilation of csrc/bsdfd.hip and, when an instruction touches the
+    destination of an asynchronous LDS read before its wait, rebuilds with -DBSDFD_NO_ASYNC_LDS instead of shipping a library
+    that could multiply with stale weights.  The check is fed a doctored verdict for the first
+    compilation; the library that comes out must be the fallback variant and say so."""
+    import ctypes as C
+    import shutil
+    if not shutil.which("hipcc"):
+        pytest.skip("needs hipcc")
+    from bsdf_diffusion_sampling_amd import _lib
+    real, calls = _lib._check_asm, []
+
+    def doctored(path):
+        calls.append(open(path).read().count("ds_read_b128"))
+        if len(calls) == 1:
+            assert real(path) == {}          # this toolchain's real build is clean ...
+            return {"flow_kernel<doctored>": ["line 1: `v_mov_b32 v50, v11` touches v11, the destination of the asynchronous read at line 0"]}
+        return real(path)                    # ... and so is the fallback build (no asynchronous reads to check)
+    monkeypatch.setattr(_lib, "_check_asm", doctored)
+    out = str(tmp_path / "libbsdfd_fallback_test.so")
+    assert _lib.build(force=True, lib_path=out) == out
+    info = _lib.build_info(out)
+    assert len(calls) == 2 and info["variant"] == "plain" and "flow_kernel<doctored>" in info["violations"]
+    assert "rebuilding the flow kernels with -DBSDFD_NO_ASYNC_LDS" in capsys.readouterr().out
+    import torch  # noqa: F401  (the HIP runtime the library links against)
+    L = C.CDLL(out)
+    L.bsdfd_version.restype = C.c_char_p
+    assert b"fallback" in L.bsdfd_version()
+    # the product library of this tree, built by the same routine, is the asynchronous variant
+    assert _lib.build_info().get("variant") == "async" and b"asynchronous LDS reads" in _lib.lib().bsdfd_version()
 
 
 def test_committed_profiles_match_the_kernel_source():

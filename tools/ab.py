@@ -114,6 +114,23 @@ def main():
         ms, mn = kernel_ms(smp, lambda: smp.plugin_sample_pdf(wi, wl, None, T=4, seed=3), a.reps)
         out["fused4"] = {"ms": ms, "min": mn}
         smp.close()
+    if "fusedsph8" in only:  # the same for a spherical net (T = 8): the kernel a spherical render uses
+        fw = W.load(W.shipped_path("aniso_miro_7_rgb", "spherical"))
+        smp = FlowSampler(fw)
+        n = 1 << 20
+        wi, wl = bench.make_wi("spherical", n, 1234, dev), bench.make_wi("spherical", n, 99, dev)
+        settle(smp, wi, 8)
+        ms, mn = kernel_ms(smp, lambda: smp.plugin_sample_pdf(wi, wl, None, T=8, seed=3), a.reps)
+        out["fusedsph8"] = {"ms": ms, "min": mn}
+        if a.acc:  # fused == two single-op launches (same seed): max relative difference of the two pdfs
+            wo, po, pl = smp.plugin_sample_pdf(wi, wl, None, T=8, seed=3)
+            wo2, po2 = smp.plugin_sample(wi, None, T=8, seed=3)
+            pl2 = smp.plugin_pdf(wi, wl, T=8)
+            def rel(u, v):
+                m = v.abs() > 1e-6 * v.abs().median()
+                return float(((u - v).abs()[m] / v.abs()[m]).quantile(0.999))
+            out["fusedsph8"]["vs_two_calls_p999"] = [float((wo - wo2).abs().max()), rel(po, po2), rel(pl, pl2)]
+        smp.close()
     if "sph8" in only:
         plug("sph8", "aniso_miro_7_rgb", "spherical", None, 1 << 22, 8)
     if "cplx8" in only:

@@ -15,13 +15,15 @@ import json
 import re
 import sys
 
-# Occupancy of a SIMD's VALU issue path, shader cycles per wave64 instruction (tools/ubench/RESULTS.md, "Round 3").
-# Round 3 replaced the additive "MFMA time + VALU time" model: PMC passes of tools/ubench/spec2 show that a
-# v_mfma_f32_16x16x32_f16 holds the VALU issue path for ~9.6 of its 16 matrix-pipe cycles (SQ_ACTIVE_INST_VALU counts 2.4
-# quad-cycles per MFMA), and tools/ubench/bank shows what the VALU classes cost at 3-4 waves/SIMD: plain VOP3 2.56, VOP2
-# 2.14, packed-f32 / converting 4.29, a transcendental 8.1 in a pure stream but ~11 between plain instructions (the
-# sigmoid chains exp -> add -> rcp -> mul measure 10.5 batched, 11.4 unit by unit).
-COST = {"v_mfma_f32_16x16x32_f16": 9.6, "v_mfma_f32_16x16x4_f32": 19.2, "v_mfma_f32_32x32x16_f16": 19.2,
+# What an instruction costs the SIMD, shader cycles per wave64 instruction at 3-4 waves/SIMD (tools/ubench/RESULTS.md).
+# Round 4 (tools/ubench/mfma_src, profiles/r04_ab/): in a VALU-heavy stream — this kernel issues ~7 VALU per MFMA — MFMA time
+# and VALU time ADD: [1 MFMA + 8 v_fma] costs 36.4 cycles = 16.4 + 8 x 2.5 whatever the operands' register file (VGPR / AGPR /
+# inline 0), the order of dependent MFMAs, or the number of co-resident waves; only up to ~2 plain VALU per MFMA hide in an
+# MFMA-bound stream.  (Round 3 had priced an MFMA at the 9.6 cycles SQ_ACTIVE_INST_VALU attributes to it; that counter counts
+# issue events in quad-cycle granules, not occupancy: it reads 97 % on a stream that is saturated by construction and would
+# read 167 % on pure v_fma.)  VALU classes: plain VOP3 2.56, VOP2 2.14, packed-f32 / converting 4.29, a transcendental 8.1 in
+# a pure stream but ~11 between plain instructions (tools/ubench/bank).
+COST = {"v_mfma_f32_16x16x32_f16": 16.35, "v_mfma_f32_16x16x4_f32": 32.0, "v_mfma_f32_32x32x16_f16": 32.1,
         "v_exp_f32": 11.0, "v_rcp_f32": 11.0, "v_log_f32": 11.0, "v_sqrt_f32": 11.0, "v_sin_f32": 11.0, "v_cos_f32": 11.0,
         "v_rsq_f32": 11.0, "v_exp_f16": 11.0, "v_rcp_f16": 11.0,
         "v_cvt_pk_f16_f32": 4.29, "v_cvt_pkrtz_f16_f32": 4.4, "v_perm_b32": 4.3, "v_cvt_f32_f16": 4.2,
@@ -42,42 +44,9 @@ def cost(m):
     return 0.0
 
 
-def kernel_body(lines, key):
-    start = None
-    for i, l in enumerate(lines):
-        if l.startswith("_Z") and key in l and l.split(";")[0].rstrip().endswith(":"):
-            start = i
-            break
-    if start is None:
-        raise SystemExit(f"kernel matching {key!r} not found")
-    for j in range(start, len(lines)):
-        if lines[j].strip().startswith("s_endpgm"):
-            return lines[start:j + 1]
-    return lines[start:]
-
-
-def loops(body):
-    """(first, last) line indices of every label .. backward-branch pair."""
-    labels = {}
-    out = []
-    for i, l in enumerate(body):
-        m = re.match(r"^(\.LBB\d+_\d+):", l)
-        if m:
-            labels[m.group(1)] = i
-        m = re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", l)
-        if m and m.group(1) in labels:
-            out.append((labels[m.group(1)], i))
-    return out
-
-
-def mix(body, lo, hi):
-    c = collections.Counter()
-    for l in body[lo:hi + 1]:
-        l = l.split(";")[0].strip()
-        if not l or l.endswith(":") or l.startswith("."):
-            continue
-        c[re.sub(r"_(e32|e64|sdwa|dpp)$", "", l.split()[0])] += 1
-    return c
+import os as _os
+sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+from bsdf_diffusion_sampling_amd._asmcheck import check_async_lines, kernel_body, loops, mix  # noqa: E402
 
 
 KERNEL_OF_WORKLOAD = {  # bench.py workload -> mangled-name fragment of its flow kernel (split3, Jacobian)
@@ -105,73 +74,25 @@ def profile(out_path):
     git = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     dirty = bool(subprocess.run(["git", "-C", root, "status", "--porcelain", "--", src], capture_output=True, text=True).stdout.strip())
     res["_meta"] = {"kernel_source_sha256": hashlib.sha256(open(src, "rb").read()).hexdigest(), "git": git + ("+dirty" if dirty else ""),
-                    "tool": "tools/isa_mix.py --profile", "cost_model": "VALU-issue-path occupancy, round 3 (see COST in tools/isa_mix.py)"}
+                    "tool": "tools/isa_mix.py --profile", "cost_model": "additive: sum of VALU costs + matrix-pipe time of the MFMAs, round 4 (see COST in tools/isa_mix.py)"}
     json.dump(res, open(out_path, "w"), indent=1)
     print(f"wrote {out_path}")
 
 
-def _regs(tok):
-    """VGPR indices named by an operand token: v12 -> {12}, v[4:7] -> {4..7}."""
-    m = re.fullmatch(r"v(\d+)", tok)
-    if m:
-        return {int(m.group(1))}
-    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
-    if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    return set()
-
-
 def check_async(path, key):
-    """The flow kernel fetches weight fragments with inline-asm `ds_read_b128` whose destinations the compiler believes valid
-    at once (csrc/bsdfd.hip, lds_read_b128_async_at); they are only valid after the next `s_waitcnt lgkmcnt(0)`.  Verify on the
-    built assembly that no instruction reads or writes a destination register in between, and that the kernel has no scratch
-    (a spill of such a register would store stale data).  Returns the list of violations (empty = safe)."""
+    """(asynchronous reads, violations) of one kernel of a built assembly file: bsdf_diffusion_sampling_amd/_asmcheck.py (the
+    check `_lib.build()` runs on its own artefact), plus the occupancy guard of the headline kernel: more than 168 VGPRs would
+    drop the 32-wide kernels from 3 to 2 waves/SIMD (csrc/bsdfd.hip, BSDFD_MIN_WAVES; -4 % when measured)."""
     lines = open(path).read().splitlines()
-    body = kernel_body(lines, key)
-    bad, pending, in_asm, n_async = [], {}, False, 0
-    for i, raw in enumerate(body):
-        l = raw.strip()
-        if l.startswith(";;#ASMSTART") or l.startswith(";#ASMSTART"):
-            in_asm = True
-            continue
-        if l.startswith(";;#ASMEND") or l.startswith(";#ASMEND"):
-            in_asm = False
-            continue
-        code = l.split(";")[0].strip()
-        if not code or code.endswith(":") or code.startswith("."):
-            continue
-        op = code.split()[0]
-        toks = [t.strip(",") for t in code.split()[1:]]
-        if op.startswith("s_waitcnt") and "lgkmcnt(0)" in code:
-            pending.clear()
-            continue
-        touched = set().union(*[_regs(t) for t in toks]) if toks else set()
-        for r in touched & set(pending):
-            bad.append(f"line {i}: `{code}` touches v{r}, the destination of the asynchronous read at line {pending[r]}")
-        if in_asm and op == "ds_read_b128":
-            n_async += 1
-            for r in _regs(toks[0]):
-                pending[r] = i
-        if op.startswith("s_cbranch") or op.startswith("s_branch") or op == "s_endpgm":
-            if pending:
-                bad.append(f"line {i}: control flow `{code}` with {len(pending)} asynchronous destination registers still pending")
-                pending.clear()
-    meta = {}
+    n, bad = check_async_lines(lines, key)
     for i, l in enumerate(lines):
         if ".name:" in l and key in l:
             for l2 in lines[i:i + 16]:
-                m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", l2)
-                if m:
-                    meta["scratch"] = int(m.group(1))
                 m = re.search(r"\.vgpr_count:\s+(\d+)", l2)
-                if m:
-                    meta["vgprs"] = int(m.group(1))
+                if m and int(m.group(1)) > 168 and "ILi2ELi" in key:
+                    bad.append(f"kernel uses {m.group(1)} VGPRs: more than the 168 that 3 waves/SIMD allow (csrc/bsdfd.hip, BSDFD_MIN_WAVES)")
             break
-    if meta.get("scratch", 0) != 0:
-        bad.append(f"kernel uses {meta['scratch']} B/lane of scratch: a spilled asynchronous destination would be stale")
-    if meta.get("vgprs", 0) > 168:
-        bad.append(f"kernel uses {meta['vgprs']} VGPRs: more than the 168 that 3 waves/SIMD allow (csrc/bsdfd.hip, BSDFD_MIN_WAVES)")
-    return n_async, bad
+    return n, bad
 
 
 def main():
@@ -190,7 +111,8 @@ def main():
             rc = 0
             for key in ("flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E", "flow_kernelILi0ELi2ELi3ELb1ELi3ELb0E",    # disk 32x3: split3, f16
                         "flow_kernelILi0ELi2ELi2ELb1ELi3ELb1E", "flow_kernelILi0ELi2ELi3ELb1ELi3ELb1E",    # ... fused sample+pdf
-                        "flow_kernelILi1ELi2ELi2ELb1ELi4ELb0E", "flow_kernelILi1ELi2ELi3ELb1ELi4ELb0E"):   # spherical 32x4
+                        "flow_kernelILi1ELi2ELi2ELb1ELi4ELb0E", "flow_kernelILi1ELi2ELi3ELb1ELi4ELb0E",    # spherical 32x4
+                        "flow_kernelILi1ELi2ELi2ELb1ELi4ELb1E", "flow_kernelILi1ELi2ELi3ELb1ELi4ELb1E"):   # ... fused sample+pdf
                 n, bad = check_async(asm, key)
                 print(f"{key}: {n} asynchronous ds_read_b128, {len(bad)} violations")
                 for b in bad:
@@ -239,8 +161,8 @@ def model(path, key):
         "matrix_pipe_cycles": round(sum(MATRIX_PIPE.get(k, 16.2) * v for k, v in mfma.items()), 1),
         "meta": meta,
     }
-    # the step is bound by the VALU issue path (MFMA issue occupancy + VALU), never by the matrix pipe itself here
-    res["issue_cycles_total"] = round(max(res["issue_cycles_mfma"] + res["issue_cycles_valu"], res["matrix_pipe_cycles"]), 1)
+    # MFMA time and VALU time add (round 4, tools/ubench/mfma_src)
+    res["issue_cycles_total"] = round(res["issue_cycles_mfma"] + res["issue_cycles_valu"], 1)
     return res
 
 
