@@ -311,18 +311,34 @@ class MixedMaterials:
         self.launches_per_pass = 4
         self.query_launches_per_pass = 2 * self.n_local
         self.precision = self.tab.samplers[0].precision
-        self.out = None
         self.ctx = {} if USE_CONTEXT else None  # per-query contexts of the wavefront's runs (MaterialTable.sample(ctx=))
+        # the wavefronts of a step are independent: bucket + gather of wavefront k+1 and the scatter of wavefront k-1 run on
+        # side streams under the flow kernels of wavefront k (materials.WavefrontPipeline); every wavefront still does all
+        # five stages inside the timed region ($BSDFD_BENCH_MIXED_SERIAL=1: the stages one after the other on one stream)
+        from bsdf_diffusion_sampling_amd.materials import WavefrontPipeline
+        self.pipe = None if os.environ.get("BSDFD_BENCH_MIXED_SERIAL") else WavefrontPipeline(self.tab)
+        self.wave = None
+        self._out = None
 
     def run_pass(self, k):
         # one bucketing and ONE gather of the inputs per wavefront; sample() and pdf() run on the bucket-ordered arrays;
         # one scatter of the three results back to the callers' lane order
         tab = self.tab
+        if self.pipe is not None:
+            self.wave = self.pipe.push(self.ids, self.wi, seed=1000 + k, offset=self.rank * self.n_local, ctx=self.ctx)
+            self._out = None
+            return
         plan = tab.bucket(self.ids)
         wi_b = tab.gather(plan, self.wi)
         wo_b, pdf_b = tab.sample(plan, wi_b, seed=1000 + k, offset=self.rank * self.n_local, bucketed=True, ctx=self.ctx)
         p_b = tab.pdf(plan, wi_b, wo_b, bucketed=True, ctx=self.ctx)
-        self.out = tab.scatter(plan, wo_b, pdf_b, p_b)
+        self._out = tab.scatter(plan, wo_b, pdf_b, p_b)
+
+    @property
+    def out(self):
+        if self._out is None and self.wave is not None:
+            self._out = self.wave.result()
+        return self._out
 
     def result(self):
         from bsdf_diffusion_sampling_amd.sharding import pack_result
@@ -338,7 +354,10 @@ class MixedMaterials:
         return {"materials": len(self.tab), "domain": "27 disk + 25 spherical", "euler_steps": "4 (disk) / 8 (spherical)",
                 "api": "MaterialTable: bucket-by-material (native counting sort), one gather of wi, segmented plugin "
                        "sample()/pdf() launches on the bucket-ordered arrays, one scatter of (wo, pdf, pdf) back to lane order "
-                       "— all inside the step", "per_query_context": self.ctx is not None}
+                       "— all inside the step", "per_query_context": self.ctx is not None,
+                "pipelined": self.pipe is not None,
+                "pipelining": "bucket + gather of wavefront k+1 and scatter of wavefront k-1 on side streams under the flow "
+                              "kernels of wavefront k (materials.WavefrontPipeline)" if self.pipe is not None else "none"}
 
 
 class Teacher:

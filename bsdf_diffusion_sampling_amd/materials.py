@@ -375,3 +375,71 @@ class MaterialTable:
                                                                              device=wi.device)
         pdf[rows] = pdf_s
         return pdf
+
+
+class _Wavefront:
+    """One wavefront in flight through a ``WavefrontPipeline``: ``result()`` orders the calling stream behind its scatter
+    and returns (wo [N,3], pdf(wo) by sample() [N], pdf(wo) by pdf() [N]) in the callers' lane order."""
+
+    def __init__(self):
+        self.plan = self.wi_b = self.bucketed = self.out = None
+        self.prep_done = self.flow_done = self.scatter_done = None
+
+    def result(self):
+        cur = torch.cuda.current_stream(self.out[0].device)
+        cur.wait_event(self.scatter_done)
+        for t in self.out:
+            t.record_stream(cur)
+        return self.out
+
+
+class WavefrontPipeline:
+    """sample() + pdf() of a STREAM of independent material-tagged wavefronts (the passes of a render, the tiles of a film),
+    software-pipelined over three HIP streams: the bucketing + gather of wavefront k run on a side stream under the flow
+    kernels of wavefront k-1 (the host's wait for the bucket counts included), its scatter on another under the flow
+    kernels of wavefront k+1.  The flow kernels — the only compute-bound part — then run back to back on the calling
+    stream; the streaming passes around them use the HBM bandwidth the flow kernels leave idle.  Results are those of
+    ``bucket -> gather -> sample(bucketed) -> pdf(bucketed) -> scatter`` issued one after the other, bit for bit.
+
+    ``push()`` returns a ``_Wavefront``; at most two are in flight: the buffers of wavefront k are reused by wavefront k+2,
+    so take ``result()`` of a wavefront before pushing the second one after it."""
+
+    def __init__(self, table: MaterialTable):
+        self.tab = table
+        self.pre = self.post = None
+        self.slots = [_Wavefront(), _Wavefront()]
+        self.k = 0
+
+    def push(self, material_id: torch.Tensor, wi: torch.Tensor, seed: int = 0, offset: int = 0,
+             ctx: Optional[dict] = None, extra_bins: int = 0) -> _Wavefront:
+        """``material_id`` / ``wi`` must be complete when this is called (they are read on a side stream that does not wait
+        for the calling stream — waiting would serialise it behind the previous wavefront's flow kernels)."""
+        tab, dev = self.tab, wi.device
+        main = torch.cuda.current_stream(dev)
+        if self.pre is None or self.pre.device != dev:
+            self.pre, self.post = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        w = self.slots[self.k % 2]
+        self.k += 1
+        with torch.cuda.stream(self.pre):
+            if w.flow_done is not None:
+                self.pre.wait_event(w.flow_done)       # the flow kernels of wavefront k-2 have read the buffers reused here
+            plan = tab.bucket(material_id, extra_bins)  # (the host waits for the counts on THIS stream only)
+            wi_b = tab.gather(plan, wi)
+            for t in (plan[0], wi_b):
+                t.record_stream(main)
+            w.plan, w.wi_b = plan, wi_b
+            w.prep_done = self.pre.record_event()
+        main.wait_event(w.prep_done)
+        if w.scatter_done is not None:
+            main.wait_event(w.scatter_done)
+        wo_b, pdf_b = tab.sample(plan, wi_b, seed=seed, offset=offset, bucketed=True, ctx=ctx)
+        p_b = tab.pdf(plan, wi_b, wo_b, bucketed=True, ctx=ctx)
+        for t in (wo_b, pdf_b, p_b, plan[0]):
+            t.record_stream(self.post)
+        w.bucketed = (wo_b, pdf_b, p_b)
+        w.flow_done = main.record_event()
+        with torch.cuda.stream(self.post):
+            self.post.wait_event(w.flow_done)
+            w.out = tab.scatter(plan, wo_b, pdf_b, p_b)
+            w.scatter_done = self.post.record_event()
+        return w

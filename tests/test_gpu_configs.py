@@ -111,3 +111,45 @@ def test_config5_matpreview_1024spp_as_8_row_tiles():
     assert ball > 0                                              # the material ball is lit
     torch.cuda.synchronize()
     print(f"config 5 at full size (2.7e8 paths, whole + 8 tiles): {time.perf_counter() - t0:.1f} s")
+
+
+def test_wavefront_pipeline_equals_the_serial_stages():
+    """materials.WavefrontPipeline (bucket + gather of wavefront k+1 and scatter of wavefront k-1 on side streams under the flow
+    kernels of wavefront k — what bench.py's mixed_16Mi workload runs): five independent wavefronts with different material
+    ids give, bit for bit, what bucket -> gather -> sample -> pdf -> scatter give one after the other on one stream; buffers
+    are recycled after two wavefronts; lanes of the extra bins come back as zeros."""
+    import torch
+    from bsdf_diffusion_sampling_amd.materials import MaterialTable, WavefrontPipeline
+    dev = _dev()
+    tab = MaterialTable(["aniso_miro_7_rgb_disk", "chm_orange_rgb_disk", "aniso_miro_7_rgb_spherical", "chm_orange_rgb_spherical",
+                         "bsdf_3_spherical"])
+    n = 300_001
+    g = torch.Generator().manual_seed(9)
+    z = 0.05 + 0.9 * torch.rand(n, generator=g)
+    ph = 6.2831853 * torch.rand(n, generator=g)
+    wi = torch.stack([torch.sqrt(1 - z * z) * torch.cos(ph), torch.sqrt(1 - z * z) * torch.sin(ph), z], 1).float().to(dev)
+    pipe = WavefrontPipeline(tab)
+    ctx_p, ctx_s = {}, {}
+    prev = None
+    for k in range(5):
+        extra = 1 if k == 3 else 0
+        ids = torch.randint(0, len(tab) + extra, (n,), generator=torch.Generator().manual_seed(100 + k)).to(dev)
+        wi_k = wi.roll(k, 0).contiguous()
+        torch.cuda.synchronize()                       # (the pipeline reads its inputs on a side stream: they must be complete)
+        w = pipe.push(ids, wi_k, seed=40 + k, offset=7 * k, ctx=ctx_p, extra_bins=extra)
+        # the same wavefront, stage by stage
+        plan = tab.bucket(ids, extra)
+        wi_b = tab.gather(plan, wi_k)
+        wo_b, pdf_b = tab.sample(plan, wi_b, seed=40 + k, offset=7 * k, bucketed=True, ctx=ctx_s)
+        p_b = tab.pdf(plan, wi_b, wo_b, bucketed=True, ctx=ctx_s)
+        ref = tab.scatter(plan, wo_b, pdf_b, p_b)
+        got = w.result()
+        torch.cuda.synchronize()
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        if extra:
+            assert (got[1][ids == len(tab)] == 0).all() and (got[0][ids == len(tab)] == 0).all()
+        assert torch.isfinite(got[2]).all() and (got[1] > 0).float().mean() > 0.5
+        if prev is not None:
+            assert prev is not w                       # two slots, alternating
+        prev = w

@@ -123,6 +123,17 @@ void row(const char* name) {
 }
 
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "pmc0")) {
+        // the same VALU stream WITHOUT the MFMAs (what SQ_ACTIVE_INST_VALU reads on pure v_fma_f32 at full rate)
+        if (!g_out) { hipMalloc(&g_out, 256 * 1024 * 4); hipMalloc(&g_cyc, 8); }
+        hipMemset(g_cyc, 0, 8);
+        const int iters = 40000;
+        k<7, 8><<<256, 768>>>(g_out, iters, g_cyc);
+        hipDeviceSynchronize();
+        long long c; hipMemcpy(&c, g_cyc, 8, hipMemcpyDeviceToHost);
+        printf("pmc0 run: [8 v_fma_f32] x %d groups per wave, 3 waves/SIMD: %.2f cycles per v_fma_f32 per SIMD\n", iters * 8, (double)c / (iters * 64.0) / 3);
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "pmc")) {
         // one saturated configuration, long enough for a counter pass (tools/r04_pmc_ubench.sh): [1 MFMA + 8 v_fma_f32] per group,
         // 3 waves/SIMD, every CU — by construction the SIMD has issuable work in every cycle
