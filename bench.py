@@ -44,8 +44,12 @@ WORKLOADS = {
     "spherical_16Mi_T8": ("single", "aniso_miro_7_rgb", "spherical", 1 << 24, 8),  # configs[2]
     "mixed_16Mi": ("mixed", "27 disk (T=4) + 25 spherical (T=8) measured materials", "mixed", 1 << 24, 0),  # configs[3] share
     "teacher_64x6_4Mi_T128": ("teacher", "aniso_miro_7_rgb", "spherical", 1 << 22, 128),
+    "complex64_1Mi_T8": ("single", "aniso_miro_7_rgb", "spherical:complex", 1 << 20, 8),  # the 64-wide x 6 net, split3, with Jacobian
 }
-SECONDARY = ("disk_1Mi_T4", "spherical_16Mi_T8", "mixed_16Mi", "teacher_64x6_4Mi_T128")
+SECONDARY = ("disk_1Mi_T4", "spherical_16Mi_T8", "mixed_16Mi", "teacher_64x6_4Mi_T128", "complex64_1Mi_T8")
+# the per-query context pays while it round-trips through the 256 MiB Infinity Cache and stops paying once it streams through
+# HBM (plugin_base.NeuralBSDFCore applies the same gate): wavefronts whose record is larger run without it
+CONTEXT_MAX_BYTES = 192 << 20
 USE_CONTEXT = os.environ.get("BSDFD_BENCH_CONTEXT", "1") != "0"  # --context off: plain sample() / pdf() calls
 
 
@@ -249,8 +253,9 @@ class SingleMaterial:
         from bsdf_diffusion_sampling_amd import weights as W
         from bsdf_diffusion_sampling_amd.sampler import FlowSampler
         _, self.material, self.domain, self.n_local, self.T = WORKLOADS[name]
+        self.domain, _, kind = self.domain.partition(":")   # "spherical:complex" = the 64-wide x 6 checkpoint of that material
         self.name, self.rank = name, rank
-        self.smp = FlowSampler(W.load(W.shipped_path(self.material, self.domain)), precision=precision)
+        self.smp = FlowSampler(W.load(W.shipped_path(self.material, self.domain, kind or None)), precision=precision)
         self.samplers = [self.smp]
         self.variant = _lib.PLUGIN_MEASURED
         n = self.n_local
@@ -266,7 +271,7 @@ class SingleMaterial:
         self.last = 0
         # per-query context (include/bsdfd.h, bsdfd_context_bytes): sample() writes what depends on wi alone, pdf() of
         # the same wavefront reads it instead of recomputing the prologue; bit-identical results (tests/test_gpu_parity.py)
-        self.ctx = self.smp.new_context(n) if USE_CONTEXT else None
+        self.ctx = self.smp.new_context(n) if USE_CONTEXT and self.smp.context_floats(n) * 4 <= CONTEXT_MAX_BYTES else None
 
     def run_pass(self, k):
         b = k & 1
@@ -749,6 +754,7 @@ def worker(a):
                 _, ms = profile_read(wl)
                 split[kind] = ms / 20
             profiling(wl, False)
+            roof["flow_launches_after_timed_region"] = 80   # (tools/summarize_profile.py slices the per-launch trace with it)
             roof.update({"algorithmic_flop_per_query": wl.smp.flops_per_query(wl.T), "sample_launch_ms": split["sample"],
                          "pdf_launch_ms": split["pdf"], "sample_Msamples_per_s": n_local / (split["sample"] * 1e-3) / 1e6,
                          "pdf_Msamples_per_s": n_local / (split["pdf"] * 1e-3) / 1e6})
@@ -771,6 +777,7 @@ def worker(a):
                     _, ms_tt = profile_read(wl)
                     loop[TT] = (ms_tt / 12, profile_clock_mhz(wl))
                     profiling(wl, False)
+                roof["flow_launches_after_timed_region"] += 36
                 # (each launch length is converted at the clock ITS launches ran at: the two may differ by a few per cent)
                 c_long = loop[2 * wl.T][0] * (loop[2 * wl.T][1] or mhz)
                 c_short = loop[wl.T][0] * (loop[wl.T][1] or mhz)

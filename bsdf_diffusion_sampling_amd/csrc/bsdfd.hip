@@ -368,6 +368,13 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
     // VGPRs, all in the per-tile prologue and at the phase switch — none inside the Euler loop and none between an
     // asynchronous read and its wait, which is what tools/isa_mix.py --check-async verifies.
     constexpr bool MIMS = JAC && NM == 2 && PREC != BSDFD_PREC_F32 && DOMAIN == BSDFD_DOMAIN_SPHERICAL && NH == 4;
+    // FOLDOUT (the depth-unrolled 64-wide instantiation, i.e. the reference's 64 x 6 nets; the run-time-depth kernels would carry
+    // the 48 extra registers across loop iterations and spill): the OUTPUT side of the Jacobian folded as in MIM — the tangents stop in front of
+    // the activation of the second-to-last hidden layer (U_i = their fp32 pre-activations there), R_j = G_j g_L with
+    // G_j = W_L^T diag(Wout[j, :]) packed by the host, J_ji = sum_k R_j[k] g_{L-1}[k] U_i[k].  Per step two tangent vectors less to
+    // scale and split (once at the second-to-last, once at the last layer) for one split of g_L, and 8 MFMAs fewer.
+    // Within-run A/B (profiles/r04_ab/ab4_foldout_64wide.txt): -0.7 % (sample) / -1.8 % (pdf) on the 64 x 6 split3 kernel.
+    constexpr bool FOLDOUT = JAC && NM == 4 && NH >= 2 && PREC != BSDFD_PREC_F32;
     // conditioning term of layer 1 on split-fp16 MFMAs: split3 builds of the DISK kernels (see the prologue).  Round 4,
     // all 77 shipped sets x 2048 queries (profiles/r04_ab/acc_sweep_*.json): the worst disk set's p99 pdf error goes from 2.4e-5
     // to 2.6e-5 (sample) and 2.3e-5 to 2.8e-5 (pdf) for -2.2 % kernel time at the plugin's T = 4 (-0.6 % at T = 8); the
@@ -389,6 +396,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
     const char* Lwo = smem + p.L.wo;
     const char* Lwf = smem + p.L.wf;
     const char* Lwf_lo = smem + p.L.wf_lo;
+    const char* Lwg = smem + p.L.wg;
+    const char* Lwg_lo = smem + p.L.wg_lo;
     const float* Lbw1 = reinterpret_cast<const float*>(smem + p.L.bw1);
     const float* Lbb1 = reinterpret_cast<const float*>(smem + p.L.bb1);
     const float* Lbw2 = reinterpret_cast<const float*>(smem + p.L.bw2);
@@ -1114,12 +1123,21 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
                 constexpr bool TWLO = SPLIT && (kTangentPrec >= 2);     // tangents: W_lo product
                 // NH > 0: fully unrolled.  NH == 0 (run-time depth) cannot be, and clang says so (-Wpass-failed,
                 // silenced in the build line); an explicit `unroll 1` there measured 13 % slower on the 64-wide net
+                const bool foldout = FOLDOUT && n_hidden >= 2;
+                float gmid[NM][4];     // FOLDOUT: silu' of the second-to-last hidden layer, the fp32 middle factor of J
+                f32x4 Uf0[NM], Uf1[NM], Rf0[NM], Rf1[NM];
 #pragma unroll
                 for (int layer = 0; layer < n_hidden; ++layer) {
                     const bool last = (layer == n_hidden - 1);
                     // first hidden layer of a disk net: folded tangents (FOLD_L1 above) — split g, not t_0 and t_1
                     const bool fold = FOLD_L1 && layer == 0 && !last;
+                    const bool pen = foldout && layer == n_hidden - 2;   // the tangents stop here (see FOLDOUT)
+                    const bool lastf = foldout && last;                  // ... and g_L alone is split: b0h / b0l hold it
                     Frag bh[KC], bl[KC], b0h[KC], b0l[KC], b1h[KC], b1l[KC];
+                    if (pen) {
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) { Uf0[m] = zt0[m]; Uf1[m] = zt1[m]; }
+                    }
 #pragma unroll
                     for (int m = 0; m < NM; ++m) {
                         float hv[4], t0v[4], t1v[4];
@@ -1128,13 +1146,16 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
                             float gg;
                             silu_grad_scaled(z[m][r], hv[r], gg);
                             if (JAC) {
-                                t0v[r] = fold ? gg : zt0[m][r] * gg;
-                                if (!fold) t1v[r] = zt1[m][r] * gg;
+                                if (pen) gmid[m][r] = gg;
+                                t0v[r] = (fold || lastf) ? gg : zt0[m][r] * gg;
+                                if (!fold && !lastf) t1v[r] = zt1[m][r] * gg;
                             }
                         }
                         const int kc = m >> 1, q0 = 2 * (m & 1);
                         split_pack<SPLIT>(hv, bh[kc].p[q0], bh[kc].p[q0 + 1], bl[kc].p[q0], bl[kc].p[q0 + 1]);
-                        if (JAC && fold) {
+                        if (JAC && pen) {
+                            // nothing to split: the tangents are consumed in fp32 by the bilinear form
+                        } else if (JAC && (fold || lastf)) {
                             split_pack<TSPLIT>(t0v, b0h[kc].p[q0], b0h[kc].p[q0 + 1], b0l[kc].p[q0], b0l[kc].p[q0 + 1]);
                         } else if (JAC) {
                             split_pack<TSPLIT>(t0v, b0h[kc].p[q0], b0h[kc].p[q0 + 1], b0l[kc].p[q0], b0l[kc].p[q0 + 1]);
@@ -1190,26 +1211,55 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
                                 }
                                 continue;
                             }
+                            const bool tang = JAC && !pen;   // (FOLDOUT: no tangent contractions out of the second-to-last layer)
 #pragma unroll
                             for (int mo = 0; mo < NM; ++mo) {
                                 a[mo] = mfma16(wh[mo], bh[kc].v, a[mo]);
-                                if (JAC) { a0[mo] = mfma16(wh[mo], b0h[kc].v, a0[mo]); a1[mo] = mfma16(wh[mo], b1h[kc].v, a1[mo]); }
+                                if (tang) { a0[mo] = mfma16(wh[mo], b0h[kc].v, a0[mo]); a1[mo] = mfma16(wh[mo], b1h[kc].v, a1[mo]); }
                             }
                             if (SPLIT) {
 #pragma unroll
                                 for (int mo = 0; mo < NM; ++mo) {
                                     a[mo] = mfma16(wh[mo], bl[kc].v, a[mo]);
-                                    if (JAC && TSPLIT) { a0[mo] = mfma16(wh[mo], b0l[kc].v, a0[mo]); a1[mo] = mfma16(wh[mo], b1l[kc].v, a1[mo]); }
+                                    if (tang && TSPLIT) { a0[mo] = mfma16(wh[mo], b0l[kc].v, a0[mo]); a1[mo] = mfma16(wh[mo], b1l[kc].v, a1[mo]); }
                                 }
 #pragma unroll
                                 for (int mo = 0; mo < NM; ++mo) {
                                     a[mo] = mfma16(wl[mo], bh[kc].v, a[mo]);
-                                    if (JAC && TWLO) { a0[mo] = mfma16(wl[mo], b0h[kc].v, a0[mo]); a1[mo] = mfma16(wl[mo], b1h[kc].v, a1[mo]); }
+                                    if (tang && TWLO) { a0[mo] = mfma16(wl[mo], b0h[kc].v, a0[mo]); a1[mo] = mfma16(wl[mo], b1h[kc].v, a1[mo]); }
                                 }
                             }
                         }
 #pragma unroll
                         for (int mo = 0; mo < NM; ++mo) { z[mo] = a[mo]; zt0[mo] = a0[mo]; zt1[mo] = a1[mo]; }
+                    } else if (lastf) {
+                        // output layer for h as below; R_j = G_j g_L (fragments of G_0, G_1 behind L.wg, hi / lo)
+                        f32x4 e = zero4;
+#pragma unroll
+                        for (int mo = 0; mo < NM; ++mo) { Rf0[mo] = zero4; Rf1[mo] = zero4; }
+#pragma unroll
+                        for (int kc = 0; kc < KC; ++kc) {
+                            const f16x8 wo = *reinterpret_cast<const f16x8*>(Lwo + ((size_t)kc * 64 + lane) * 16);
+                            e = mfma16(wo, bh[kc].v, e);
+                            if (SPLIT) e = mfma16(wo, bl[kc].v, e);
+                            constexpr size_t gstride = (size_t)NM * KC * 64 * 16;
+#pragma unroll
+                            for (int mo = 0; mo < NM; ++mo) {
+                                const size_t goff = ((size_t)(mo * KC + kc) * 64 + lane) * 16;
+                                const f16x8 g0h = *reinterpret_cast<const f16x8*>(Lwg + goff);
+                                const f16x8 g1h = *reinterpret_cast<const f16x8*>(Lwg + gstride + goff);
+                                Rf0[mo] = mfma16(g0h, b0h[kc].v, Rf0[mo]);
+                                Rf1[mo] = mfma16(g1h, b0h[kc].v, Rf1[mo]);
+                                if (TSPLIT) { Rf0[mo] = mfma16(g0h, b0l[kc].v, Rf0[mo]); Rf1[mo] = mfma16(g1h, b0l[kc].v, Rf1[mo]); }
+                                if (TWLO) {
+                                    const f16x8 g0l = *reinterpret_cast<const f16x8*>(Lwg_lo + goff);
+                                    const f16x8 g1l = *reinterpret_cast<const f16x8*>(Lwg_lo + gstride + goff);
+                                    Rf0[mo] = mfma16(g0l, b0h[kc].v, Rf0[mo]);
+                                    Rf1[mo] = mfma16(g1l, b0h[kc].v, Rf1[mo]);
+                                }
+                            }
+                        }
+                        v[0] = e[0] + e[2]; v[1] = e[1] + e[3];
                     } else {
                         // output layer: A rows (i&3) = {Wout_hi[0], Wout_hi[1], Wout_lo[0], Wout_lo[1]}, so
                         // e[0..1] = hi*hi + hi*lo and e[2..3] = lo*hi (+ lo*lo, ~2^-22): out = e[o] + e[o+2]
@@ -1229,10 +1279,11 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
                         d1[0] = e1[0] + e1[2]; d1[1] = e1[1] + e1[3];
                     }
                 }
+                if (foldout) mim_finish(Rf0, Rf1, gmid, Uf0, Uf1);
             }
 
             // det(I + c*J) with the row convention of mlp_brdf_sampling.py:44-46; signed.
-            if (JAC && !MIM && !MIMS) {
+            if (JAC && !MIM && !MIMS && !(FOLDOUT && n_hidden >= 2)) {
                 const float j00 = 1.0f + cstep * d0[0];
                 const float j01 = cstep * d1[0];
                 const float j10 = cstep * d0[1];
@@ -1389,8 +1440,11 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
     // ... and the output side folded the same way (MIM in the kernel), with W_L the last hidden-to-hidden matrix:
     // G_j = W_L^T diag(Wout[j, :]), j = 0, 1, so that (Wout D_L W_L)^T[:, j] = G_j g_L
     // (disk 25-32x3-2 and spherical 26-32x4-2: the two nets the reference's plugins load)
-    const bool mim = prec != BSDFD_PREC_F32 && NM == 2 &&
-                     ((d.domain == BSDFD_DOMAIN_DISK && NH == 3) || (d.domain == BSDFD_DOMAIN_SPHERICAL && NH == 4));
+    // (disk 25-32x3-2 and spherical 26-32x4-2: the two nets the reference's plugins load — compile-time fragment offsets; and
+    //  the 64 x 6 spherical net, which has a depth-unrolled instantiation: FOLDOUT in the kernel, run-time offsets)
+    const bool mim32 = prec != BSDFD_PREC_F32 && NM == 2 &&
+                       ((d.domain == BSDFD_DOMAIN_DISK && NH == 3) || (d.domain == BSDFD_DOMAIN_SPHERICAL && NH == 4));
+    const bool mim = mim32 || (prec != BSDFD_PREC_F32 && NM == 4 && NH == 6 && d.domain == BSDFD_DOMAIN_SPHERICAL);
     if (fold) {
         L.wf = off; off += NFOLD * NM * KC * 64 * 16;
         L.wf_lo = off;
@@ -1401,6 +1455,7 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
         L.wg_lo = off;
         if (prec == BSDFD_PREC_SPLIT3) off += NFOLD * NM * KC * 64 * 16;
         // the MIM kernels address their fragments with compile-time offsets: keep the two in step
+        if (mim32) {
         const int fr = 64 * 16, o_wh = NM * 64 * 4 + NM * PE_SLABS * 64 * 4, o_whl = o_wh + (NH - 1) * NM * fr;
         const bool sp = prec == BSDFD_PREC_SPLIT3;
         const int o_wo = sp ? o_whl + (NH - 1) * NM * fr : o_whl;
@@ -1410,6 +1465,7 @@ std::vector<char> build_image(const bsdfd_desc& d_in, int prec, ImgLayout& L) {
             L.wg_lo != o_wgl) {
             L.total = -1;  // reported by bsdfd_create as an error: never launch a kernel whose fragment offsets are wrong
             return {};
+        }
         }
     }
     L.bw1 = off; off += (BASE_PE_BANDS + 1) * 64 * 4;

@@ -47,6 +47,7 @@ def test_bench_line_single_gpu_with_secondary_and_cpu_baseline():
     assert d["config"]["timed_region_s"] >= 0.45                     # sized at setup, whatever --steps is
     ib = d["roofline"]["issue_bound"]
     assert 1000 < ib["shader_clock_mhz"] < 2500, ib
+    assert abs(ib["probe_clock_mhz"] / ib["shader_clock_mhz"] - 1) < 0.08, ib      # in-kernel counters vs the stand-alone probe kernel
     # the issue model and the HBM traffic are looked up from committed profiles that carry the kernel source's fingerprint;
     # tests/test_host_cpu.py::test_committed_profiles_match_the_kernel_source keeps them current
     assert ib["model_source"]["status"] == "current" and 0.5 < ib["frac_of_issue_bound"] < 1.3, ib
@@ -55,7 +56,7 @@ def test_bench_line_single_gpu_with_secondary_and_cpu_baseline():
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["all_cores"]["cores"] >= cb["cores"]
     ac = cb["all_cores"]  # a child process with a time budget: a figure, or an honest "did not finish" with an upper bound
     assert (ac["value"] is not None and ac["value"] > 0) or (ac["timed_passes_finished"] == 0 and ac["value_upper_bound"] > 0)
-    for name in ("disk_1Mi_T4", "spherical_16Mi_T8", "mixed_16Mi", "teacher_64x6_4Mi_T128"):
+    for name in ("disk_1Mi_T4", "spherical_16Mi_T8", "mixed_16Mi", "teacher_64x6_4Mi_T128", "complex64_1Mi_T8"):
         s = d["secondary"][name]
         assert "error" not in s, s
         assert s["value"] > 0 and 0 < s["frac"] < 1

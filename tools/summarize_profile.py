@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    tag, name = sys.argv[1], sys.argv[2]
+    tag, name = sys.argv[1], sys.argv[2]   # tools/summarize_profile.py <prof tag> <output name> [workload]
     workload = sys.argv[3] if len(sys.argv) > 3 else "disk_1Mi_T8"
     src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(ROOT, "profiles")
@@ -49,17 +49,40 @@ def main():
         out["bench_line"] = {k: bench[k] for k in ("value", "ms_per_step", "steps") if k in bench}
         out["bench_line"]["roofline"] = {k: bench["roofline"].get(k) for k in ("avg_launch_ms", "frac", "launches")}
         out["bench_line"]["passes_per_step"] = bench["config"].get("passes_per_step", 1)
+        n_timed = int(bench["roofline"].get("launches", 2 * steps))
+        n_after = int(bench["roofline"].get("flow_launches_after_timed_region", 0))
     except Exception:
-        pass
+        n_timed, n_after = 2 * steps, 10
     tr = glob.glob(os.path.join(src, "trace", "trace_kernel_trace.csv"))
     if tr and "kernel_trace" in out:
         rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr[0]))
                 if "flow_kernel" in r["Kernel_Name"]]
         rows.sort()
-        timed = rows[-(2 * steps + 10):-10]  # bench.py: ..., 2*steps timed launches, then 5 sample + 5 pdf
+        # bench.py: ..., the timed region's launches, then the per-kind split and the T / 2T pair of the issue-bound entry
+        timed = rows[-(n_timed + n_after):len(rows) - n_after]
         if timed:
             out["kernel_trace"]["timed_region_launches"] = len(timed)
             out["kernel_trace"]["timed_region_avg_ns"] = sum(e - b for b, e in timed) / len(timed)
+    # shader clock three ways in ONE run (the GRBM pass): GRBM_GUI_ACTIVE / 8 XCDs / the dispatch's own duration, the flow
+    # kernel's in-kernel figure (bsdfd_profile_clock_mhz) and the stand-alone probe, both from the JSON line that run printed
+    try:
+        f = glob.glob(os.path.join(src, "pmc_GRBM*", "pmc_counter_collection.csv"))[0]
+        mhz = [float(r["Counter_Value"]) / 8.0 / max(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), 1) * 1e3
+               for r in csv.DictReader(open(f)) if "flow_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "GRBM_GUI_ACTIVE"]
+        clk = {"grbm_gui_active_mhz": sum(mhz) / len(mhz), "launches": len(mhz),
+               "basis": "GRBM_GUI_ACTIVE / 8 XCDs / (End_Timestamp - Start_Timestamp) per flow-kernel dispatch of the GRBM pass"}
+        logf = glob.glob(os.path.join(src, "pmc_GRBM*.log"))[0]
+        line = json.loads([l for l in open(logf) if l.startswith("{")][-1])
+        ib = line["roofline"].get("issue_bound", {})
+        clk["in_kernel_mhz_same_run"] = ib.get("shader_clock_mhz")
+        clk["probe_mhz_same_run"] = ib.get("probe_clock_mhz")
+        if clk["in_kernel_mhz_same_run"]:
+            clk["in_kernel_over_grbm"] = clk["in_kernel_mhz_same_run"] / clk["grbm_gui_active_mhz"]
+        if clk["probe_mhz_same_run"]:
+            clk["probe_over_grbm"] = clk["probe_mhz_same_run"] / clk["grbm_gui_active_mhz"]
+        out["shader_clock"] = clk
+    except Exception as exc:  # (a trace-only directory has no GRBM pass)
+        out["shader_clock"] = {"error": repr(exc)}
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         # rocprofv3 reports KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B: double it
         # (MI355X_MICROARCH.md §HBM; calibrated on this kernel's known 12/24 B-per-query reads)
