@@ -1389,8 +1389,8 @@ struct bsdfd_ctx {
     long long n_done;      // launches harvested
     double total_ms;
     float last_ms;
-    unsigned long long* d_clk;  // RING x 2 counters (KParams::clk)
-    double total_cycles, total_ticks;  // sums over harvested launches of the waves' lifetimes: shader cycles, wall-clock ticks
+    unsigned long long* d_clk;  // 2 cumulative counters (KParams::clk), zeroed by bsdfd_set_profiling — NOT per launch: a memset in
+                                // front of every profiled launch would put an inter-kernel boundary inside the event bracket
     double wall_khz;            // rate of the wall clock (hipDeviceAttributeWallClockRate)
 };
 
@@ -1639,13 +1639,8 @@ hipError_t harvest(bsdfd_handle h, int slot) {
     float ms = 0.f;
     e = hipEventElapsedTime(&ms, h->ev0[slot], h->ev1[slot]);
     if (e != hipSuccess) return e;
-    unsigned long long st[2];
-    e = hipMemcpy(st, h->d_clk + (size_t)slot * 2, sizeof st, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return e;
     h->pending[slot] = false;
     h->total_ms += ms;
-    h->total_cycles += (double)st[0];
-    h->total_ticks += (double)st[1];
     h->last_ms = ms;
     h->n_done++;
     return hipSuccess;
@@ -1775,8 +1770,7 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
         if (h->profiling) {
             slot = (int)(h->n_rec % bsdfd_ctx::RING);
             if (h->pending[slot]) HIP_TRY(harvest(h, slot));
-            kp.clk = h->d_clk + (size_t)slot * 2;
-            HIP_TRY(hipMemsetAsync(kp.clk, 0, 2 * sizeof(unsigned long long), s));
+            kp.clk = h->d_clk;
             HIP_TRY(hipEventRecord(h->ev0[slot], s));
         }
     }
@@ -1853,7 +1847,7 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     h->in_dim = h->state_dim + 1 + 2 + 4 * PE_BANDS;
     h->device = dev; h->num_cu = prop.multiProcessorCount;
     h->profiling = false; h->d_img = nullptr; h->d_clk = nullptr;
-    h->n_rec = h->n_done = 0; h->total_ms = 0.0; h->last_ms = -1.0f; h->total_cycles = h->total_ticks = 0.0;
+    h->n_rec = h->n_done = 0; h->total_ms = 0.0; h->last_ms = -1.0f;
     {
         int khz = 0;
         h->wall_khz = hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess ? (double)khz : 0.0;
@@ -1870,7 +1864,7 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_img), img.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_img, img.data(), img.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_clk), (size_t)bsdfd_ctx::RING * 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_clk), 2 * sizeof(unsigned long long));
     for (int i = 0; i < bsdfd_ctx::RING && e == hipSuccess; ++i) {
         e = hipEventCreate(&h->ev0[i]);
         if (e == hipSuccess) e = hipEventCreate(&h->ev1[i]);
@@ -2097,8 +2091,8 @@ int bsdfd_set_profiling(bsdfd_handle h, int32_t enable) {
     h->profiling = enable != 0;
     h->n_rec = h->n_done = 0;
     h->total_ms = 0.0;
-    h->total_cycles = h->total_ticks = 0.0;
     h->last_ms = -1.0f;
+    HIP_TRY(hipMemset(h->d_clk, 0, 2 * sizeof(unsigned long long)));  // (every pending launch was harvested above: nothing is in flight)
     return BSDFD_OK;
 }
 
@@ -2120,7 +2114,9 @@ int bsdfd_profile_clock_mhz(bsdfd_handle h, double* mhz) {
     int rc = bsdfd_profile_read(h, nullptr, nullptr);
     if (rc != BSDFD_OK) return rc;
     std::lock_guard<std::mutex> lock(h->prof_mu);
-    *mhz = (h->total_ticks > 0.0 && h->wall_khz > 0.0) ? h->total_cycles / h->total_ticks * h->wall_khz * 1e-3 : 0.0;
+    unsigned long long st[2] = {0, 0};   // (bsdfd_profile_read has synchronised on every recorded launch)
+    HIP_TRY(hipMemcpy(st, h->d_clk, sizeof st, hipMemcpyDeviceToHost));
+    *mhz = (st[1] > 0 && h->wall_khz > 0.0) ? (double)st[0] / (double)st[1] * h->wall_khz * 1e-3 : 0.0;
     return BSDFD_OK;
 }
 
