@@ -731,7 +731,7 @@ def worker(a):
                 "traffic_note": "with the per-query context on, a sample launch also WRITES and a pdf launch also READS the context "
                                 "(144 B/query for the 32-wide nets) = 5.1x the 28 algorithmic bytes, by design: it replaces the "
                                 "prologue's recomputation; HBM stays below 5 % of its bandwidth",
-                "kernel": "flow_kernel", "launches": n_launch, "avg_launch_ms": avg_ms,
+                "kernel": "flow_kernel", "launches": n_launch, "avg_launch_ms": avg_ms, "shader_clock_mhz": kern_mhz,
                 "algorithmic_flop_per_launch": flops_launch, "queries_per_launch": n_local,
                 "kernel_Msamples_per_s": wl.query_launches_per_pass * R * a.steps / (kern_ms * 1e-3) / 1e6,
                 "kernel_Msamples_basis": "queries x flow-kernel launches each goes through (sample and pdf count separately) "

@@ -74,7 +74,7 @@ def main():
         logf = glob.glob(os.path.join(src, "pmc_GRBM*.log"))[0]
         line = json.loads([l for l in open(logf) if l.startswith("{")][-1])
         ib = line["roofline"].get("issue_bound", {})
-        clk["in_kernel_mhz_same_run"] = ib.get("shader_clock_mhz")
+        clk["in_kernel_mhz_same_run"] = ib.get("shader_clock_mhz") or line["roofline"].get("shader_clock_mhz")
         clk["probe_mhz_same_run"] = ib.get("probe_clock_mhz")
         if clk["in_kernel_mhz_same_run"]:
             clk["in_kernel_over_grbm"] = clk["in_kernel_mhz_same_run"] / clk["grbm_gui_active_mhz"]
