@@ -66,6 +66,7 @@ enum { OP_SAMPLE = 0, OP_PDF = 1, OP_SAMPLES_ONLY = 2, OP_SAMPLE_PDF = 3 };  // 
 // 7e-4 .. 8e-3 — the 2x2 determinant of a sharp lobe cancels heavily); the ablation builds live in git history
 // (commit 5a33ef0), not in the product source.
 constexpr int kTangentPrec = 3;
+constexpr int CLK_SLOTS = 256;  // counter pairs of the in-kernel clock measurement, 8 u64 (one 64-B line) apart
 constexpr int MAX_SEG = 64;  // materials per segmented launch (the descriptors travel in the kernel arguments)
 enum { IO_OPERATOR = 0, IO_PLUGIN = 1, IO_PLUGIN_FULLSPHERE = 2 };
 
@@ -99,9 +100,10 @@ struct KParams {
     // sample: Philox counter of row i = offset + rng_index[i] (NULL: offset + i).  A bucketed wavefront passes the rows'
     // ORIGINAL lane indices, so the draws do not depend on the bucketing, the sharding or the GPU count
     const long long* rng_index;
-    // profiling only (else NULL): every wave adds its lifetime in shader cycles (s_memtime) to clk[0] and in ticks of the
-    // constant-rate wall clock (s_memrealtime) to clk[1]; their ratio is the shader clock the kernel ran at
-    // (bsdfd_profile_clock_mhz).  Both counters are read by the same wave, so per-CU counter offsets cancel.
+    // profiling only (else NULL): every wave adds its lifetime in shader cycles (s_memtime) and in ticks of the constant-rate
+    // wall clock (s_memrealtime) to one of CLK_SLOTS counter pairs (one 64-B line each: 16 Ki same-address atomics per launch
+    // cost a 0.25 ms launch 6 %); the ratio of the sums is the shader clock the kernel ran at (bsdfd_profile_clock_mhz).
+    // Both counters are read by the same wave, so per-CU counter offsets cancel.
     unsigned long long* clk;
     int seg_base;    // segmented launches: buckets served by EARLIER launches of the same call (context slot numbering)
     int chunk_log2;  // a wave takes 2^chunk_log2 consecutive-ish tiles per chunk (see the tile map in the kernel)
@@ -1351,7 +1353,11 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
     if (p.clk) {
         const unsigned long long dc = (unsigned long long)__builtin_readcyclecounter() - clk_c0;
         const unsigned long long dr = (unsigned long long)__builtin_amdgcn_s_memrealtime() - clk_r0;
-        if ((threadIdx.x & 63) == 0) { atomicAdd(p.clk, dc); atomicAdd(p.clk + 1, dr); }
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long* slot = p.clk + 8 * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (CLK_SLOTS - 1));
+            atomicAdd(slot, dc);
+            atomicAdd(slot + 1, dr);
+        }
     }
 }
 
@@ -1389,7 +1395,7 @@ struct bsdfd_ctx {
     long long n_done;      // launches harvested
     double total_ms;
     float last_ms;
-    unsigned long long* d_clk;  // 2 cumulative counters (KParams::clk), zeroed by bsdfd_set_profiling — NOT per launch: a memset in
+    unsigned long long* d_clk;  // CLK_SLOTS x 8 cumulative counters (KParams::clk), zeroed by bsdfd_set_profiling — NOT per launch: a memset in
                                 // front of every profiled launch would put an inter-kernel boundary inside the event bracket
     double wall_khz;            // rate of the wall clock (hipDeviceAttributeWallClockRate)
 };
@@ -1864,7 +1870,8 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_img), img.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_img, img.data(), img.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_clk), 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_clk), (size_t)CLK_SLOTS * 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->d_clk, 0, (size_t)CLK_SLOTS * 8 * sizeof(unsigned long long));
     for (int i = 0; i < bsdfd_ctx::RING && e == hipSuccess; ++i) {
         e = hipEventCreate(&h->ev0[i]);
         if (e == hipSuccess) e = hipEventCreate(&h->ev1[i]);
@@ -2092,7 +2099,7 @@ int bsdfd_set_profiling(bsdfd_handle h, int32_t enable) {
     h->n_rec = h->n_done = 0;
     h->total_ms = 0.0;
     h->last_ms = -1.0f;
-    HIP_TRY(hipMemset(h->d_clk, 0, 2 * sizeof(unsigned long long)));  // (every pending launch was harvested above: nothing is in flight)
+    HIP_TRY(hipMemset(h->d_clk, 0, (size_t)CLK_SLOTS * 8 * sizeof(unsigned long long)));  // (every pending launch was harvested above: nothing is in flight)
     return BSDFD_OK;
 }
 
@@ -2114,9 +2121,11 @@ int bsdfd_profile_clock_mhz(bsdfd_handle h, double* mhz) {
     int rc = bsdfd_profile_read(h, nullptr, nullptr);
     if (rc != BSDFD_OK) return rc;
     std::lock_guard<std::mutex> lock(h->prof_mu);
-    unsigned long long st[2] = {0, 0};   // (bsdfd_profile_read has synchronised on every recorded launch)
-    HIP_TRY(hipMemcpy(st, h->d_clk, sizeof st, hipMemcpyDeviceToHost));
-    *mhz = (st[1] > 0 && h->wall_khz > 0.0) ? (double)st[0] / (double)st[1] * h->wall_khz * 1e-3 : 0.0;
+    std::vector<unsigned long long> st((size_t)CLK_SLOTS * 8);   // (bsdfd_profile_read has synchronised on every recorded launch)
+    HIP_TRY(hipMemcpy(st.data(), h->d_clk, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double cyc = 0.0, ticks = 0.0;
+    for (int i = 0; i < CLK_SLOTS; ++i) { cyc += (double)st[(size_t)i * 8]; ticks += (double)st[(size_t)i * 8 + 1]; }
+    *mhz = (ticks > 0.0 && h->wall_khz > 0.0) ? cyc / ticks * h->wall_khz * 1e-3 : 0.0;
     return BSDFD_OK;
 }
 
