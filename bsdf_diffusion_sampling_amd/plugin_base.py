@@ -98,7 +98,10 @@ class NeuralBSDFCore:
         # queries, 2.4 GB: -1 %), so larger wavefronts run without it.
         self.context_cache = bool(get("context_cache", True))
         self.context_cache_max_bytes = int(get("context_cache_max_bytes", 192 << 20))
-        self._ctx = None        # (key, wi tensor, buffer) of the last launch that FILLED the buffer successfully
+        # (key, wi tensor, buffer) of the last launch that FILLED the buffer successfully.  The entry keeps a reference to the
+        # tensor it was filled for (12 B per query next to the 144 B of the record): its storage cannot be freed and handed to
+        # another tensor — same pointer, version 0 again — while the entry lives.
+        self._ctx = None
         self._ctx_buf = None
         self._ctx_event = None  # recorded behind every launch that touched the buffer (cross-stream ordering)
         self._ctx_stream = None
