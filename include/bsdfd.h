@@ -203,7 +203,9 @@ int bsdfd_flow_samples_only(bsdfd_handle h, const float* omega_i, const float* x
  * that is still running).  bsdfd_set_profiling resets the counters.
  * bsdfd_profile_read synchronises on the outstanding stop events and returns the number of
  * launches and the sum of their durations (ms) since profiling was enabled;
- * bsdfd_last_kernel_ms returns the duration of the most recent launch (negative if none). */
+ * bsdfd_last_kernel_ms returns the duration of the most recent launch (negative if none).
+ * bsdfd_set_profiling / bsdfd_profile_* synchronise and touch device memory from the host: not while a stream is being captured
+ * (launches THROUGH a profiling handle are capture-safe only with profiling off: event records inside a capture become graph nodes). */
 int bsdfd_set_profiling(bsdfd_handle h, int32_t enable);
 int bsdfd_profile_read(bsdfd_handle h, int64_t* n_launches, double* total_ms);
 float bsdfd_last_kernel_ms(bsdfd_handle h);
