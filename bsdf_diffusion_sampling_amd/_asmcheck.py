@@ -141,7 +141,102 @@ def check_async_lines(lines: List[str], key: str) -> Tuple[int, List[str]]:
     return n_async, bad
 
 
+# Wait states (issued instructions; `s_nop N` counts N + 1) the ISA requires between an MFMA and a later non-MFMA instruction
+# that READS its destination registers (passes + 2) or, for a VALU instruction, OVERWRITES them (passes + 3 for the XDL
+# shapes, passes + 2 for the f32-input ones); a pass = 4 cycles (CDNA3 ISA guide §4.5; LLVM GCNHazardRecognizer::
+# checkMAIVALUHazards; the numbers are the ones hipcc itself pads to in straight-line code).  A branch counts as ONE wait state
+# although a taken branch costs more in practice: the check errs on the safe side.  An intervening MFMA counts as its own number
+# of passes (the matrix pipe runs a wave's MFMAs back to back).  The compiler inserts them — but hipcc 7.2 was caught
+# leaving them out on one path (round 4: an MFMA directly in front of a taken `s_cbranch`, its result read two instructions into
+# the target block: the kernel computed with the stale accumulator), so the build checks.  A load whose DESTINATION is the
+# register is not a hazard (its data returns long after the matrix pipe has drained).
+# opcode -> (wait states before a read, before a VALU overwrite)
+MFMA_WAIT = {"v_mfma_f32_16x16x32_f16": (6, 7), "v_mfma_f32_16x16x32_bf16": (6, 7), "v_mfma_f32_16x16x16_f16": (4, 5),
+             "v_mfma_f32_16x16x4_f32": (10, 10), "v_mfma_f32_32x32x16_f16": (10, 11), "v_mfma_f32_32x32x2_f32": (18, 18)}
+MFMA_WAIT_DEFAULT = (18, 19)
+_LOADS = ("ds_read", "global_load", "scratch_load", "buffer_load", "flat_load", "s_load", "s_buffer_load")
+
+
+def _is_mfma(op: str) -> bool:
+    return op.startswith("v_mfma") or op.startswith("v_smfmac")
+
+
+def check_mfma_hazards_lines(lines: List[str], key: str) -> Tuple[int, List[str]]:
+    """(number of MFMAs, violations): every non-MFMA instruction that reads (or, VALU, overwrites) a destination register of
+    an MFMA must be the required number of wait states behind it on EVERY path (fall-through and branch targets are both
+    followed).  MFMAs that take the result as an operand are exempt (the matrix pipe interlocks its own dependent issue)."""
+    body = kernel_body(lines, key)
+    ins, label_at = [], {}
+    for raw in body:
+        code = raw.split(";")[0].strip()
+        if not code or code.startswith("."):
+            m = re.match(r"^(\.LBB\d+_\d+):", raw)
+            if m:
+                label_at[m.group(1)] = len(ins)
+            continue
+        if code.endswith(":"):
+            label_at[code[:-1]] = len(ins)
+            continue
+        toks = [t.strip(",") for t in code.split()]
+        ins.append((toks[0], toks[1:], code))
+    n_mfma, bad = 0, []
+    for i, (op, toks, code) in enumerate(ins):
+        if not _is_mfma(op):
+            continue
+        n_mfma += 1
+        need_r, need_w = MFMA_WAIT.get(re.sub(r"_(e32|e64)$", "", op), MFMA_WAIT_DEFAULT)
+        dst = _regs(toks[0]) if toks else set()
+        if not dst:
+            continue
+        stack, seen = [(i + 1, 0)], {}
+        while stack:
+            j, w = stack.pop()
+            while j < len(ins) and w < max(need_r, need_w):
+                if seen.get(j, 1 << 30) <= w:
+                    break
+                seen[j] = w
+                o, t, c = ins[j]
+                if not _is_mfma(o) and t:
+                    has_dst = o.startswith("v_") and not o.startswith("v_cmp") and not o.startswith("v_readlane") \
+                        and not o.startswith("v_readfirstlane")
+                    is_load = o.startswith(_LOADS)
+                    writes = _regs(t[0]) if (has_dst or is_load) else set()
+                    reads = set().union(*[_regs(x) for x in (t[1:] if (has_dst or is_load) else t)]) if t else set()
+                    if o.startswith("v_writelane") or o.startswith("v_fmac") or o.startswith("v_pk_fmac"):
+                        reads |= writes          # read-modify-write destinations
+                    if (dst & reads and w < need_r) or (dst & writes and has_dst and w < need_w):
+                        kind = "reads" if dst & reads else "overwrites"
+                        bad.append(f"`{c}` {kind} the destination of `{code}` after {w} wait states "
+                                   f"(needs {need_r if kind == 'reads' else need_w})")
+                        stack.clear()
+                        break
+                    if dst <= writes and not (dst & reads):
+                        break                    # fully redefined: later uses see the new value
+                if o == "s_endpgm":
+                    break
+                m = re.search(r"(\.LBB\d+_\d+)", c) if o.startswith("s_cbranch") or o == "s_branch" else None
+                if m and m.group(1) in label_at:
+                    stack.append((label_at[m.group(1)], w + 1))
+                    if o == "s_branch":
+                        break
+                if o == "s_nop" and t:
+                    w += int(t[0], 0) + 1
+                elif _is_mfma(o):   # the matrix pipe runs the wave's MFMAs back to back: one cannot issue before the previous has had its passes
+                    w += MFMA_WAIT.get(re.sub(r"_(e32|e64)$", "", o), MFMA_WAIT_DEFAULT)[0] - 2
+                else:
+                    w += 1
+                j += 1
+    return n_mfma, bad
+
+
 def check_file(path: str, fragment: str = "flow_kernel") -> Dict[str, Tuple[int, List[str]]]:
-    """Every kernel of the assembly file whose name contains ``fragment`` -> (asynchronous reads, violations)."""
+    """Every kernel of the assembly file whose name contains ``fragment`` -> (asynchronous reads, violations of the
+    asynchronous-read discipline)."""
     lines = open(path).read().splitlines()
     return {k: check_async_lines(lines, k) for k in kernel_names(lines, fragment)}
+
+
+def check_file_mfma(path: str, fragment: str = "flow_kernel") -> Dict[str, Tuple[int, List[str]]]:
+    """Every kernel of the assembly file whose name contains ``fragment`` -> (MFMAs, missing-wait-state violations)."""
+    lines = open(path).read().splitlines()
+    return {k: check_mfma_hazards_lines(lines, k) for k in kernel_names(lines, fragment)}

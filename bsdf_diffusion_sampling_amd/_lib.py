@@ -86,6 +86,15 @@ def _check_asm(asm_path: str):
     return {k: bad for k, (n, bad) in _asmcheck.check_file(asm_path).items() if bad}
 
 
+def _check_asm_mfma(asm_path: str):
+    """Instructions that read or overwrite an MFMA's destination before the wait states the ISA requires
+    (``_asmcheck.check_file_mfma``): {kernel: [messages]}.  The compiler is supposed to pad for these; ROCm 7.2 was caught
+    leaving the padding out behind a taken branch (csrc/bsdfd.hip, the base-net MFMAs), silently computing with a stale
+    accumulator — there is no fallback for this class, the build refuses to ship."""
+    from . import _asmcheck
+    return {k: bad for k, (n, bad) in _asmcheck.check_file_mfma(asm_path).items() if bad}
+
+
 def _compile_flow_tu(td: str, extra, verbose: bool):
     """Compile csrc/bsdfd.hip to td/bsdfd.o keeping the device assembly of THIS compilation (-save-temps=obj)."""
     import glob
@@ -108,7 +117,8 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
     allocation (csrc/bsdfd.hip, lds_read_b128_async_at), so the build verifies the assembly of its own compilation
     (``_asmcheck``) and, if that fails, REBUILDS the kernels with ``-DBSDFD_NO_ASYNC_LDS`` (compiler-managed LDS loads, ~2 %
     slower) instead of shipping a library that could read stale weights.  ``<lib>.build.json`` and ``bsdfd_version()`` say
-    which variant shipped."""
+    which variant shipped.  The same assembly is also checked for MFMA results that are consumed before their wait states have
+    passed (``_check_asm_mfma``); that check has no fallback: a violation aborts the build."""
     import json
     import tempfile
     out = lib_path or LIB_PATH
@@ -151,6 +161,13 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
                 still = _check_asm(asm)
                 if still:
                     raise RuntimeError(f"the fallback build still fails the assembly check: {still}")
+            hz = _check_asm_mfma(asm)
+            if hz:
+                first = next(iter(hz.items()))
+                raise RuntimeError("bsdfd build: this toolchain's compilation of csrc/bsdfd.hip reads or overwrites MFMA results "
+                                   f"before the wait states the ISA requires, in {len(hz)} kernel(s) — e.g. {first[0]}: {first[1][0]}.  "
+                                   "The library would compute with stale accumulators; refusing to ship it "
+                                   "(bsdf_diffusion_sampling_amd/_asmcheck.py: check_mfma_hazards_lines).")
         finally:
             for cmd, pr in procs:
                 if pr.wait() != 0:

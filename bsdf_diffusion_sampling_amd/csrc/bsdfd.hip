@@ -237,6 +237,26 @@ __device__ __forceinline__ float sel4(int g, float a0, float a1, float a2, float
     return g == 0 ? a0 : (g == 1 ? a1 : (g == 2 ? a2 : a3));
 }
 
+// Scalar functions of the per-query prologue / epilogue on the hardware transcendentals (round 4: libm's versions are a measurable
+// part of the ~100 us a 1 Mi-query spherical launch spends outside its Euler steps, tools/fixed_cost.py).  v_log_f32 / v_exp_f32 are
+// 1-ulp log2 / exp2: ln x = ln 2 * log2 x carries <= 2 ulp + 1e-7 |ln x|, far inside the 1e-4 contract (the density tests hold the
+// results to 2e-5 of the fp64 oracle).
+__device__ __forceinline__ float fast_log(float x) { return kLn2 * __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
+// acos on [-1, 1] for the von Mises SAMPLER only (Abramowitz & Stegun 4.4.46, |error| <= 2e-8 + the hardware sqrt's ulp): the
+// value is the sample itself — its density is evaluated at whatever comes out — so 1e-7 of absolute error is immaterial there.
+// (cart_to_spher keeps libm's acosf / atan2f: their error is amplified by the encoder's 2^4 and by the flow.)
+__device__ __forceinline__ float fast_acos(float x) {
+#pragma clang fp contract(off)
+    const float a = fabsf(x);
+    float p = -0.0012624911f;
+    p = fmaf(p, a, 0.0066700901f); p = fmaf(p, a, -0.0170881256f); p = fmaf(p, a, 0.0308918810f);
+    p = fmaf(p, a, -0.0501743046f); p = fmaf(p, a, 0.0889789874f); p = fmaf(p, a, -0.2145988016f);
+    p = fmaf(p, a, 1.5707963050f);
+    const float r = __builtin_amdgcn_sqrtf(fmaxf(1.0f - a, 0.0f)) * p;
+    return x < 0.0f ? 3.14159265358979323846f - r : r;
+}
+
 // log I0(kappa): the two polynomials of torch.distributions.von_mises._log_modified_bessel_fn
 // (torch 2.10; call site rendering/utils/model.py:314), split at 3.75.
 __device__ __forceinline__ float log_i0(float k) {
@@ -246,18 +266,19 @@ __device__ __forceinline__ float log_i0(float k) {
         float p = 0.0045813f;
         p = fmaf(p, y, 0.0360768f); p = fmaf(p, y, 0.2659732f); p = fmaf(p, y, 1.2067492f);
         p = fmaf(p, y, 3.0899424f); p = fmaf(p, y, 3.5156229f); p = fmaf(p, y, 1.0f);
-        return logf(p);
+        return fast_log(p);
     }
-    const float y = 3.75f / k;
+    const float y = 3.75f * __builtin_amdgcn_rcpf(k);
     float p = 0.00392377f;
     p = fmaf(p, y, -0.01647633f); p = fmaf(p, y, 0.02635537f); p = fmaf(p, y, -0.02057706f);
     p = fmaf(p, y, 0.00916281f); p = fmaf(p, y, -0.00157565f); p = fmaf(p, y, 0.00225319f);
     p = fmaf(p, y, 0.01328592f); p = fmaf(p, y, 0.39894228f);
-    return k - 0.5f * logf(k) + logf(p);
+    return k - 0.5f * fast_log(k) + fast_log(p);
 }
 
 __device__ __forceinline__ float softplus(float x) {  // nn.Softplus(beta=1, threshold=20)
-    return x > 20.0f ? x : log1pf(expf(x));
+    // (1 + e^x loses e^x's low bits for x << 0: an ABSOLUTE error <= 6e-8 on kappa = softplus + 1e-3, i.e. <= 1.2e-7 on log p)
+    return x > 20.0f ? x : fast_log(1.0f + fast_exp(x));
 }
 
 // Best & Fisher rejection sampler for VonMises(mu, kappa)
@@ -272,13 +293,19 @@ __device__ __forceinline__ float softplus(float x) {  // nn.Softplus(beta=1, thr
 //   16 queries of a geometric trip count with acceptance >= 0.66).
 __device__ __forceinline__ float von_mises_sample(float mu, float kappa, unsigned k0, unsigned k1, unsigned q_lo,
                                                   unsigned q_hi, int lane) {
+    // No implicit fma contraction in here: the accept test is a comparison, and a product fused in one kernel instantiation but
+    // not in another would flip it for the occasional query — every instantiation (single-op, fused, segmented) must draw the
+    // same sample for the same Philox counter.
+#pragma clang fp contract(off)
     float r;
+    // (hardware rcp / sqrt / log / cos and the polynomial acos: r only shapes the envelope, the accept test is a comparison of
+    //  random numbers, and the accepted angle is the sample itself — ulp-level differences change nothing statistically)
     if (kappa < 1e-5f) {
-        r = 1.0f / kappa + kappa;
+        r = __builtin_amdgcn_rcpf(kappa) + kappa;
     } else {
-        const float tau = 1.0f + sqrtf(1.0f + 4.0f * kappa * kappa);
-        const float rho = 2.0f * kappa / (tau + sqrtf(2.0f * tau));
-        r = (1.0f + rho * rho) / (2.0f * rho);
+        const float tau = 1.0f + __builtin_amdgcn_sqrtf(1.0f + 4.0f * kappa * kappa);
+        const float rho = 2.0f * kappa * __builtin_amdgcn_rcpf(tau + __builtin_amdgcn_sqrtf(2.0f * tau));
+        r = (1.0f + rho * rho) * __builtin_amdgcn_rcpf(2.0f * rho);
     }
     const int g = lane >> 4, q = lane & 15;
     float x = 0.0f;
@@ -287,11 +314,11 @@ __device__ __forceinline__ float von_mises_sample(float mu, float kappa, unsigne
         unsigned u[4];
         philox4x32(k0, k1, q_lo, q_hi, round * 4u + (unsigned)g + 1u, 0x564d6973u, u);  // "VMis"
         const float u1 = u01_open(u[0]), u2 = u01_open(u[1]), u3 = u01_open(u[2]);
-        const float z = cospif(u1);
-        const float f = (1.0f + r * z) / (r + z);
+        const float z = __builtin_amdgcn_cosf(0.5f * u1);   // v_cos_f32 takes revolutions: cos(pi u1)
+        const float f = (1.0f + r * z) * __builtin_amdgcn_rcpf(r + z);
         const float c = kappa * (r - f);
-        const bool accept = (c * (2.0f - c) - u2 > 0.0f) || (logf(c / u2) + 1.0f - c >= 0.0f);
-        const float a = acosf(fminf(fmaxf(f, -1.0f), 1.0f));
+        const bool accept = (c * (2.0f - c) - u2 > 0.0f) || (fast_log(c * __builtin_amdgcn_rcpf(u2)) + 1.0f - c >= 0.0f);
+        const float a = fast_acos(fminf(fmaxf(f, -1.0f), 1.0f));
         const float cand = (u3 - 0.5f) < 0.0f ? -a : a;
         const unsigned long long acc_mask = __builtin_amdgcn_ballot_w64(accept);
         const unsigned long long mine = (acc_mask >> q) & 0x0001000100010001ull;  // bit 16 g' = lane (g', q)
@@ -301,8 +328,10 @@ __device__ __forceinline__ float von_mises_sample(float mu, float kappa, unsigne
         if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
     }
     const float two_pi = 6.28318530717958647692f, pi = 3.14159265358979323846f;
-    float w = fmodf(x + pi + mu, two_pi);
+    const float t = x + pi + mu;
+    float w = fmaf(-two_pi, floorf(t * (1.0f / two_pi)), t);   // t mod 2 pi, in [0, 2 pi) up to rounding
     if (w < 0.0f) w += two_pi;
+    if (w >= two_pi) w -= two_pi;
     return w - pi;
 }
 
@@ -579,6 +608,13 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
             bo = *reinterpret_cast<const f32x4*>(Lbb2);
 #pragma unroll
             for (int r = 0; r < 4; ++r) bo = mfma4(w2[r], silu(bz[r]), bo);
+            // The result of an 8-pass MFMA may not be read by a VALU instruction for 10 wait states.  hipcc pads for that in
+            // straight-line code but was caught (ROCm 7.2, round 4) leaving the padding out when the first reader sits in a
+            // block reached by a TAKEN branch right behind the MFMA — here: the context store is skipped, softplus(bo[3]) / the
+            // base density read bo two instructions later, and the kernel computed with the stale accumulator (the bias).  The
+            // wait states are therefore spelled out; `_asmcheck.check_mfma_hazards_lines` verifies every MFMA of every
+            // instantiation on the built assembly (a branch counted as one wait state) as part of `_lib.build()`.
+            asm volatile("s_nop 7\n\ts_nop 1" : "+v"(bo));
         }
         if (!FUSED && p.ctx_out != nullptr) {  // one 1-KiB store per accumulator and wave, 16 B per query for bo
             f32x4* c = reinterpret_cast<f32x4*>(p.ctx_out) + ctx_slot * CTX_V4;
@@ -633,9 +669,11 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
                 const float e1 = (a1 - bo[1]) * fexp(-bo[3]);
                 return fexp(-log2pi - (bo[2] + bo[3]) - 0.5f * (e0 * e0 + e1 * e1));
             } else {                            // model.py:308-317
-                const float e = (a0 - bo[0]) / (fexp(bo[1]) + 1e-3f);
+                const float e = (a0 - bo[0]) * __builtin_amdgcn_rcpf(fexp(bo[1]) + 1e-3f);
                 const float loggau = -0.5f * log2pi - bo[1] - 0.5f * e * e;
-                const float logvon = kappa * cosf(a1 - bo[2]) - log2pi - log_i0(kappa);
+                float sd_, cd_;
+                sincos_enc(a1 - bo[2], sd_, cd_);   // (bounded-argument kernel, 9e-8; libm beyond |arg| 1024)
+                const float logvon = kappa * cd_ - log2pi - log_i0(kappa);
                 return fexp(loggau + logvon);
             }
         };
@@ -1339,7 +1377,9 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
             } else {
                 const float inv = fminf(fmaxf(1.0f / wo_sin, 1.0f), 3.402823466e+38f);
                 if (p.io == IO_PLUGIN) {  // rendering/brdf_measured_spherical.py:122-137
-                    if (!(sinf(xs0) > 0.00005f)) pdf = 0.0f;
+                    float s0_, c0_;
+                    sincos_enc(xs0, s0_, c0_);
+                    if (!(s0_ > 0.00005f)) pdf = 0.0f;
                     pdf_sa = (wi_z > 0.0f && wo_z > 0.0f) ? pdf * inv : 0.0f;
                 } else {                  // rendering/bsdf_myresult.py:115-133
                     pdf_sa = pdf * inv;

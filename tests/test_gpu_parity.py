@@ -501,8 +501,11 @@ def test_fused_sample_pdf_equals_the_two_calls(stem, variant):
         wo, p = s.plugin_sample(wi, x0, T=T, variant=variant, seed=3, offset=11)
         pl = s.plugin_pdf(wi, wl, T=T, variant=variant)
         wo2, p2, pl2 = s.plugin_sample_pdf(wi, wl, x0, T=T, variant=variant, seed=3, offset=11)
-        assert torch.allclose(wo, wo2, rtol=0, atol=2e-6)
-        assert same_density(p2, p) and same_density(pl2, pl)   # (forward-mode Jacobian vs meet-in-the-middle: fp32 noise)
+        # (two different instruction streams of the same arithmetic: the compiler contracts a*b+c into an fma in one and not in
+        #  the other here and there, and the flow amplifies the last bit — measured <= 4.3e-6; a flipped von Mises accept test or a
+        #  wrong lane would be O(1))
+        assert torch.allclose(wo, wo2, rtol=0, atol=1e-5)
+        assert same_density(p2, p) and same_density(pl2, pl)
     with pytest.raises(RuntimeError, match="sample_pdf|null|wl"):
         from bsdf_diffusion_sampling_amd import _lib
         import ctypes as C

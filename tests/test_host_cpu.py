@@ -347,6 +347,7 @@ def test_asynchronous_lds_reads_are_not_touched_before_their_wait():
                        timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(", 0 violations") == 8 and "25 asynchronous" in r.stdout and "21 asynchronous" in r.stdout
+    assert "MFMA results consumed before their wait states: 0 of 54 kernels" in r.stdout
 
 
 _ASM_OK = """
@@ -386,6 +387,52 @@ def test_asmcheck_flags_a_touched_asynchronous_destination(tmp_path):
     f = tmp_path / "k.s"
     f.write_text(_ASM_OK)
     assert A.check_file(str(f)) == {"_ZN12_GLOBAL__N_111flow_kernelILi0ELi2ELi2ELb1ELi3ELb0EEEvNS_7KParamsE": (1, [])}
+
+
+_ASM_HAZARD = """
+_ZN12_GLOBAL__N_111flow_kernelILi1ELi2ELi2ELb1ELi4ELb0EEEvNS_7KParamsE:
+\tv_mfma_f32_16x16x4_f32 v[10:13], v29, v0, v[30:33]
+\ts_cbranch_vccnz .LBB0_2
+\tglobal_store_dwordx4 v[24:25], v[14:17], off
+\ts_nop 7
+.LBB0_2:
+\ts_waitcnt vmcnt(0)
+\tv_mul_f32_e32 v0, 0x3fb8aa3b, v13
+\ts_endpgm
+"""
+
+
+def test_asmcheck_flags_an_mfma_result_read_before_its_wait_states():
+    """The pattern hipcc 7.2 emitted in round 4 (an MFMA right in front of a taken branch, its result read two instructions into
+    the target block): flagged; with the padding in place, with an intervening MFMA, or when the reader is another MFMA: clean."""
+    from bsdf_diffusion_sampling_amd import _asmcheck as A
+    key = "flow_kernelILi1ELi2ELi2ELb1ELi4ELb0E"
+    n, bad = A.check_mfma_hazards_lines(_ASM_HAZARD.splitlines(), key)
+    assert n == 1 and len(bad) == 1 and "reads the destination" in bad[0] and "after 2 wait states (needs 10)" in bad[0]
+    ok = _ASM_HAZARD.replace("\ts_waitcnt vmcnt(0)", "\ts_waitcnt vmcnt(0)\n\ts_nop 7")
+    assert A.check_mfma_hazards_lines(ok.splitlines(), key) == (1, [])
+    ok2 = _ASM_HAZARD.replace("\ts_waitcnt vmcnt(0)", "\ts_waitcnt vmcnt(0)\n\tv_mfma_f32_16x16x4_f32 v[40:43], v29, v0, v[40:43]")   # + 8 passes of matrix-pipe time
+    assert A.check_mfma_hazards_lines(ok2.splitlines(), key)[1] == []
+    ok3 = _ASM_HAZARD.replace("\tv_mul_f32_e32 v0, 0x3fb8aa3b, v13", "\tv_mfma_f32_16x16x4_f32 v[10:13], v29, v0, v[10:13]")
+    assert A.check_mfma_hazards_lines(ok3.splitlines(), key)[1] == []
+    waw = _ASM_HAZARD.replace("\tv_mul_f32_e32 v0, 0x3fb8aa3b, v13", "\tv_mov_b32_e32 v12, 0")
+    assert "overwrites" in A.check_mfma_hazards_lines(waw.splitlines(), key)[1][0]
+    ld = _ASM_HAZARD.replace("\tv_mul_f32_e32 v0, 0x3fb8aa3b, v13", "\tds_read_b128 v[10:13], v5")            # a load INTO the register: no hazard
+    assert A.check_mfma_hazards_lines(ld.splitlines(), key)[1] == []
+
+
+def test_build_refuses_to_ship_when_mfma_results_are_consumed_too_early(tmp_path, monkeypatch):
+    import shutil
+    if not shutil.which("hipcc"):
+        pytest.skip("needs hipcc")
+    from bsdf_diffusion_sampling_amd import _lib
+    assert _lib._check_asm_mfma.__doc__
+    monkeypatch.setattr(_lib, "_check_asm_mfma", lambda path: {"flow_kernel<doctored>": ["`v_mul_f32 v0, v13` reads the destination of "
+                                                                                        "`v_mfma_f32_16x16x4_f32 v[10:13]` after 2 wait states (needs 10)"]})
+    out = str(tmp_path / "libbsdfd_never.so")
+    with pytest.raises(RuntimeError, match="refusing to ship"):
+        _lib.build(force=True, lib_path=out)
+    assert not os.path.exists(out)
 
 
 def test_build_falls_back_to_compiler_managed_lds_reads_when_the_asm_check_fails(tmp_path, monkeypatch, capsys):

@@ -46,7 +46,7 @@ def cost(m):
 
 import os as _os
 sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
-from bsdf_diffusion_sampling_amd._asmcheck import check_async_lines, kernel_body, loops, mix  # noqa: E402
+from bsdf_diffusion_sampling_amd._asmcheck import check_async_lines, check_file_mfma, kernel_body, loops, mix  # noqa: E402
 
 
 KERNEL_OF_WORKLOAD = {  # bench.py workload -> mangled-name fragment of its flow kernel (split3, Jacobian)
@@ -118,6 +118,13 @@ def main():
                 for b in bad:
                     print("  ", b)
                 rc |= bool(bad) or n == 0
+            hz = check_file_mfma(asm)
+            n_bad = sum(1 for _, b in hz.values() if b)
+            print(f"MFMA results consumed before their wait states: {n_bad} of {len(hz)} kernels, {sum(n for n, _ in hz.values())} MFMAs checked")
+            for k, (_, b) in hz.items():
+                for x in b[:2]:
+                    print("  ", k, x)
+            rc |= bool(n_bad)
         return rc
     print(json.dumps(model(sys.argv[1], sys.argv[2]), indent=1))
 
