@@ -427,6 +427,20 @@ def profile_read(wl):
     return n_tot, ms_tot
 
 
+def profile_read_by_op(wl):
+    """{kind: (launches, total kernel ms)} of the profiled launches, by kind of launch (bsdfd_profile_read_op)."""
+    out = {}
+    for kind in ("sample", "pdf", "samples_only", "sample_pdf"):
+        n_tot, ms_tot = 0, 0.0
+        for s in wl.samplers:
+            n, ms = s.profile_read_op(kind)
+            n_tot += n
+            ms_tot += ms
+        if n_tot:
+            out[kind] = (n_tot, ms_tot)
+    return out
+
+
 def profile_clock_mhz(wl):
     """Shader clock (MHz) the chip sustained under the profiled launches themselves (bsdfd_profile_clock_mhz: the waves' own
     shader-cycle over wall-clock counters), launch-time-weighted over the handles of the workload."""
@@ -667,6 +681,7 @@ def worker(a):
     dt = region(judged_mode, a.warmup * R)
     n_launch, kern_ms = profile_read(wl)
     kern_mhz = profile_clock_mhz(wl)   # the clock of the judged launches themselves (in-kernel cycle stamps / HIP-event time)
+    by_op = profile_read_by_op(wl)     # the same launches by kind (sample / pdf / ...)
     profiling(wl, False)
     wl.check()
     extra_regions = {}
@@ -737,27 +752,14 @@ def worker(a):
                 "kernel_Msamples_basis": "queries x flow-kernel launches each goes through (sample and pdf count separately) "
                                          "/ summed kernel time"}
         if isinstance(wl, SingleMaterial):
-            # informational split of the two launch kinds (outside the timed region)
-            split = {}
-            for kind in ("sample", "pdf"):
-                def one(k):
-                    if kind == "sample":
-                        wl.smp.plugin_sample(wl.wi, None, T=wl.T, variant=wl.variant, seed=77 + k, out=(wl.wo[0], wl.pdf_s[0]), ctx_out=wl.ctx)
-                    else:
-                        wl.smp.plugin_pdf(wl.wi, wl.wo[0], T=wl.T, variant=wl.variant, out=wl.pdf_p[0], ctx_in=wl.ctx)
-                for k in range(20):   # (back-to-back launches of ONE kind draw a different clock than the mixed timed region:
-                    one(k)            #  let it settle before the 20 that are timed)
-                torch.cuda.synchronize()
-                profiling(wl, True)
-                for k in range(20):
-                    one(20 + k)
-                _, ms = profile_read(wl)
-                split[kind] = ms / 20
-            profiling(wl, False)
-            roof["flow_launches_after_timed_region"] = 80   # (tools/summarize_profile.py slices the per-launch trace with it)
-            roof.update({"algorithmic_flop_per_query": wl.smp.flops_per_query(wl.T), "sample_launch_ms": split["sample"],
-                         "pdf_launch_ms": split["pdf"], "sample_Msamples_per_s": n_local / (split["sample"] * 1e-3) / 1e6,
-                         "pdf_Msamples_per_s": n_local / (split["pdf"] * 1e-3) / 1e6})
+            # the two launch kinds of the timed region itself (the library keeps the event totals per kind of launch)
+            split = {k: ms / n for k, (n, ms) in by_op.items()}
+            roof["flow_launches_after_timed_region"] = 0   # (tools/summarize_profile.py slices the per-launch trace with it)
+            roof.update({"algorithmic_flop_per_query": wl.smp.flops_per_query(wl.T), "sample_launch_ms": split.get("sample"),
+                         "pdf_launch_ms": split.get("pdf"),
+                         "sample_pdf_split_basis": "the timed region's own launches by kind (bsdfd_profile_read_op)",
+                         "sample_Msamples_per_s": n_local / (split["sample"] * 1e-3) / 1e6 if split.get("sample") else None,
+                         "pdf_Msamples_per_s": n_local / (split["pdf"] * 1e-3) / 1e6 if split.get("pdf") else None})
             # issue-bound view: measured SIMD cycles per (16-query tile x Euler step) vs the instruction-issue model
             try:
                 probe_mhz = _lib.shader_clock_mhz()

@@ -36,7 +36,7 @@ EXPORTS = (
     "bsdfd_gather_lanes", "bsdfd_scatter_lanes",
     "bsdfd_measured_create_from_file", "bsdfd_measured_destroy", "bsdfd_measured_get_info", "bsdfd_measured_eval",
     "bsdfd_measured_sample_weight",
-    "bsdfd_set_profiling", "bsdfd_profile_read", "bsdfd_profile_clock_mhz", "bsdfd_last_kernel_ms", "bsdfd_shader_clock_mhz",
+    "bsdfd_set_profiling", "bsdfd_profile_read", "bsdfd_profile_read_op", "bsdfd_profile_clock_mhz", "bsdfd_last_kernel_ms", "bsdfd_shader_clock_mhz",
     "bsdfd_last_error", "bsdfd_version",
 )
 
@@ -256,6 +256,7 @@ def lib():
     L.bsdfd_scatter_lanes.argtypes = [fp, i64, fp, fp, fp, fp, fp, fp, vp]
     L.bsdfd_set_profiling.argtypes = [vp, i32]
     L.bsdfd_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double)]
+    L.bsdfd_profile_read_op.argtypes = [vp, C.c_int32, C.POINTER(i64), C.POINTER(C.c_double)]
     L.bsdfd_profile_clock_mhz.argtypes = [vp, C.POINTER(C.c_double)]
     L.bsdfd_last_kernel_ms.argtypes = [vp]
     L.bsdfd_last_kernel_ms.restype = C.c_float

@@ -1435,6 +1435,9 @@ struct bsdfd_ctx {
     long long n_done;      // launches harvested
     double total_ms;
     float last_ms;
+    int op_of[RING];       // which operation a recorded launch ran (OP_*): the per-operation totals of bsdfd_profile_read_op
+    long long n_op[4];
+    double ms_op[4];
     unsigned long long* d_clk;  // CLK_SLOTS x 8 cumulative counters (KParams::clk), zeroed by bsdfd_set_profiling — NOT per launch: a memset in
                                 // front of every profiled launch would put an inter-kernel boundary inside the event bracket
     double wall_khz;            // rate of the wall clock (hipDeviceAttributeWallClockRate)
@@ -1689,6 +1692,8 @@ hipError_t harvest(bsdfd_handle h, int slot) {
     h->total_ms += ms;
     h->last_ms = ms;
     h->n_done++;
+    h->n_op[h->op_of[slot] & 3]++;
+    h->ms_op[h->op_of[slot] & 3] += ms;
     return hipSuccess;
 }
 
@@ -1826,6 +1831,7 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     if (slot >= 0) {
         HIP_TRY(hipEventRecord(h->ev1[slot], s));
         h->pending[slot] = true;
+        h->op_of[slot] = op;
         h->n_rec++;
     }
     return BSDFD_OK;
@@ -1894,6 +1900,7 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     h->device = dev; h->num_cu = prop.multiProcessorCount;
     h->profiling = false; h->d_img = nullptr; h->d_clk = nullptr;
     h->n_rec = h->n_done = 0; h->total_ms = 0.0; h->last_ms = -1.0f;
+    for (int i = 0; i < 4; ++i) { h->n_op[i] = 0; h->ms_op[i] = 0.0; }
     {
         int khz = 0;
         h->wall_khz = hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess ? (double)khz : 0.0;
@@ -2139,6 +2146,7 @@ int bsdfd_set_profiling(bsdfd_handle h, int32_t enable) {
     h->n_rec = h->n_done = 0;
     h->total_ms = 0.0;
     h->last_ms = -1.0f;
+    for (int i = 0; i < 4; ++i) { h->n_op[i] = 0; h->ms_op[i] = 0.0; }
     HIP_TRY(hipMemset(h->d_clk, 0, (size_t)CLK_SLOTS * 8 * sizeof(unsigned long long)));  // (every pending launch was harvested above: nothing is in flight)
     return BSDFD_OK;
 }
@@ -2153,6 +2161,16 @@ int bsdfd_profile_read(bsdfd_handle h, int64_t* n_launches, double* total_ms) {
     }
     if (n_launches) *n_launches = h->n_done;
     if (total_ms) *total_ms = h->total_ms;
+    return BSDFD_OK;
+}
+
+int bsdfd_profile_read_op(bsdfd_handle h, int32_t op, int64_t* n_launches, double* total_ms) {
+    if (op < 0 || op > 3) return fail(BSDFD_EINVAL, "op must be one of BSDFD_OP_SAMPLE, _PDF, _SAMPLES_ONLY, _SAMPLE_PDF");
+    int rc = bsdfd_profile_read(h, nullptr, nullptr);
+    if (rc != BSDFD_OK) return rc;
+    std::lock_guard<std::mutex> lock(h->prof_mu);
+    if (n_launches) *n_launches = h->n_op[op];
+    if (total_ms) *total_ms = h->ms_op[op];
     return BSDFD_OK;
 }
 

@@ -160,6 +160,14 @@ class FlowSampler:
         _lib.check(self._L.bsdfd_profile_read(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def profile_read_op(self, op: str):
+        """(launches, total kernel ms) of ONE kind of launch since ``set_profiling(True)``: ``op`` is "sample", "pdf",
+        "samples_only" or "sample_pdf" (bsdfd_profile_read_op)."""
+        n, ms = C.c_int64(), C.c_double()
+        code = {"sample": 0, "pdf": 1, "samples_only": 2, "sample_pdf": 3}[op]
+        _lib.check(self._L.bsdfd_profile_read_op(self._h, code, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def profile_clock_mhz(self) -> float:
         """Shader clock (MHz) the chip sustained under THIS handle's launches since ``set_profiling(True)``: the waves' own
         shader-cycle / wall-clock counters (bsdfd_profile_clock_mhz); 0 if none were recorded."""

@@ -209,6 +209,14 @@ int bsdfd_flow_samples_only(bsdfd_handle h, const float* omega_i, const float* x
 int bsdfd_set_profiling(bsdfd_handle h, int32_t enable);
 int bsdfd_profile_read(bsdfd_handle h, int64_t* n_launches, double* total_ms);
 float bsdfd_last_kernel_ms(bsdfd_handle h);
+/* The same totals for ONE kind of launch (bench.py's sample / pdf split of the timed region itself): `op` is
+ * BSDFD_OP_SAMPLE (network_sampling, plugin_sample), BSDFD_OP_PDF (network_pdf, plugin_pdf), BSDFD_OP_SAMPLES_ONLY
+ * (flow_samples_only) or BSDFD_OP_SAMPLE_PDF (plugin_sample_pdf).  No counterpart in the reference. */
+#define BSDFD_OP_SAMPLE 0
+#define BSDFD_OP_PDF 1
+#define BSDFD_OP_SAMPLES_ONLY 2
+#define BSDFD_OP_SAMPLE_PDF 3
+int bsdfd_profile_read_op(bsdfd_handle h, int32_t op, int64_t* n_launches, double* total_ms);
 /* Shader clock (MHz) the chip sustained UNDER THE PROFILED LAUNCHES THEMSELVES: while profiling is enabled every wave adds its
  * lifetime in shader cycles (s_memtime) and in ticks of the constant-rate wall clock (s_memrealtime,
  * hipDeviceAttributeWallClockRate) to two words of the handle — both read by the same wave, so counter offsets between CUs

@@ -52,6 +52,8 @@ def test_bench_line_single_gpu_with_secondary_and_cpu_baseline():
     # tests/test_host_cpu.py::test_committed_profiles_match_the_kernel_source keeps them current
     assert ib["model_source"]["status"] == "current" and 0.5 < ib["frac_of_issue_bound"] < 1.3, ib
     assert d["roofline"]["traffic_source"]["status"] == "current" and d["roofline"]["traffic"] > 0
+    r = d["roofline"]   # the sample / pdf split is the timed region's own: it averages to the judged launch time
+    assert abs((r["sample_launch_ms"] + r["pdf_launch_ms"]) / 2 - r["avg_launch_ms"]) < 1e-3 * r["avg_launch_ms"], r
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["all_cores"]["cores"] >= cb["cores"]
     ac = cb["all_cores"]  # a child process with a time budget: a figure, or an honest "did not finish" with an upper bound

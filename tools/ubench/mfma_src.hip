@@ -96,6 +96,44 @@ __global__ __launch_bounds__(768) void kord(float* out, int iters, long long* cy
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicMax((unsigned long long*)cyc, (unsigned long long)(t1 - t0));
 }
 
+
+// Round 4, second question: does the issue-path hold scale with the MFMA's passes or is it per instruction?  The same group
+// test with v_mfma_f32_32x32x16_f16 (twice the flops, 16 passes) and, for reference, v_mfma_f32_16x16x16_f16 (half, 4 passes... on
+// gfx950 8) — cycles per [1 MFMA + K v_fma_f32] group per SIMD.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int SHAPE, int K>
+__global__ __launch_bounds__(768) void kshape(float* out, int iters, long long* cyc) {
+    float a[8];
+    for (int j = 0; j < 8; ++j) a[j] = threadIdx.x * 1e-3f + j;
+    f32x16 c[2];
+    for (int j = 0; j < 2; ++j) for (int i = 0; i < 16; ++i) c[j][i] = a[i & 7];
+    f32x4 d[4];
+    for (int j = 0; j < 4; ++j) d[j] = (f32x4){a[0], a[1], a[2], a[3]};
+    f16x8 h0, h1;
+    for (int j = 0; j < 8; ++j) { h0[j] = (_Float16)(a[0] + j); h1[j] = (_Float16)(a[1] - j); }
+    f16x4 g0 = {h0[0], h0[1], h0[2], h0[3]}, g1 = {h1[0], h1[1], h1[2], h1[3]};
+    long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (SHAPE == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c[u & 1]) : "v"(h0), "v"(h1));
+            if (SHAPE == 1) asm volatile("v_mfma_f32_16x16x16_f16 %0, %1, %2, %0" : "+v"(d[u & 3]) : "v"(g0), "v"(g1));
+            if (SHAPE == 2) asm volatile("v_mfma_f32_32x32x8_f16 %0, %1, %2, %0" : "+v"(c[u & 1]) : "v"(g0), "v"(g1));
+            if (SHAPE == 3) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d[u & 3]) : "v"(h0), "v"(h1));
+#pragma unroll
+            for (int f = 0; f < K; ++f) FMA(a[(u * K + f) & 7]);
+        }
+    }
+    long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+    for (int j = 0; j < 8; ++j) s += a[j];
+    for (int j = 0; j < 2; ++j) for (int i = 0; i < 16; ++i) s += c[j][i];
+    for (int j = 0; j < 4; ++j) s += d[j][0] + d[j][1] + d[j][2] + d[j][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicMax((unsigned long long*)cyc, (unsigned long long)(t1 - t0));
+}
+
 static float* g_out = nullptr;
 static long long* g_cyc = nullptr;
 template <typename F>
@@ -114,6 +152,17 @@ template <int MODE, int K>
 double run(int w) { return timeit([&](int it) { k<MODE, K><<<256, 256 * w>>>(g_out, it, g_cyc); }, 1000, 8.0, w); }
 template <int ORDER, int K>
 double runo(int w) { return timeit([&](int it) { kord<ORDER, K><<<256, 256 * w>>>(g_out, it, g_cyc); }, 1000, 4.0, w); }
+
+template <int SHAPE, int K>
+double runs(int w) { return timeit([&](int it) { kshape<SHAPE, K><<<256, 256 * w>>>(g_out, it, g_cyc); }, 1000, 8.0, w); }
+template <int SHAPE>
+void rowshape(const char* name) {
+    printf("%-10s |", name);
+    for (int w : {1, 2, 3})
+        printf(" w=%d: K=0 %5.1f K=4 %5.1f K=8 %5.1f K=12 %5.1f K=16 %5.1f K=24 %5.1f |", w, runs<SHAPE, 0>(w), runs<SHAPE, 4>(w), runs<SHAPE, 8>(w),
+               runs<SHAPE, 12>(w), runs<SHAPE, 16>(w), runs<SHAPE, 24>(w));
+    printf("\n");
+}
 
 template <int MODE>
 void row(const char* name) {
@@ -144,6 +193,11 @@ int main(int argc, char** argv) {
         hipDeviceSynchronize();
         long long c; hipMemcpy(&c, g_cyc, 8, hipMemcpyDeviceToHost);
         printf("pmc run: [1 MFMA + 8 v_fma_f32] x %d groups per wave, 3 waves/SIMD: %.1f cycles per group per SIMD\n", iters * 8, (double)c / (iters * 8.0) / 3);
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "shapes")) {
+        printf("cycles per [1 MFMA + K v_fma_f32] group per SIMD by MFMA shape (w = waves/SIMD)\n");
+        rowshape<3>("16x16x32"); rowshape<0>("32x32x16"); rowshape<1>("16x16x16"); rowshape<2>("32x32x8");
         return 0;
     }
     printf("cycles per [1 MFMA 16x16x32 f16 + K v_fma_f32] group per SIMD (w = waves/SIMD)\n");
