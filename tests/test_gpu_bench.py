@@ -47,7 +47,9 @@ def test_bench_line_single_gpu_with_secondary_and_cpu_baseline():
     assert d["config"]["timed_region_s"] >= 0.45                     # sized at setup, whatever --steps is
     ib = d["roofline"]["issue_bound"]
     assert 1000 < ib["shader_clock_mhz"] < 2500, ib
-    assert abs(ib["probe_clock_mhz"] / ib["shader_clock_mhz"] - 1) < 0.08, ib      # in-kernel counters vs the stand-alone probe kernel
+    # in-kernel counters (within 1 % of GRBM_GUI_ACTIVE in every profiled run, profiles/r04_*_pmc.json) vs the stand-alone probe
+    # kernel, which is only reported next to them: it has read 1-6 % high on some boxes of the pool and 7-9 % low on others
+    assert abs(ib["probe_clock_mhz"] / ib["shader_clock_mhz"] - 1) < 0.15, ib
     # the issue model and the HBM traffic are looked up from committed profiles that carry the kernel source's fingerprint;
     # tests/test_host_cpu.py::test_committed_profiles_match_the_kernel_source keeps them current
     assert ib["model_source"]["status"] == "current" and 0.5 < ib["frac_of_issue_bound"] < 1.3, ib
