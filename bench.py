@@ -316,7 +316,10 @@ class MixedMaterials:
         self.launches_per_pass = 4
         self.query_launches_per_pass = 2 * self.n_local
         self.precision = self.tab.samplers[0].precision
-        self.ctx = {} if USE_CONTEXT else None  # per-query contexts of the wavefront's runs (MaterialTable.sample(ctx=))
+        # per-query contexts of the wavefront's runs (MaterialTable.sample(ctx=)) — under the same size gate as everywhere: at 16 Mi
+        # queries the records (2.3 GB) stream through HBM, which measures neutral (profiles/r04_ab/mixed_ctx.txt: fewer cycles, lower clock)
+        ctx_bytes = sum(c * self.tab.samplers[m].context_floats(1 << 20) * 4 // (1 << 20) for m, c in enumerate(counts))
+        self.ctx = {} if USE_CONTEXT and ctx_bytes <= CONTEXT_MAX_BYTES else None
         # the wavefronts of a step are independent: bucket + gather of wavefront k+1 and the scatter of wavefront k-1 run on
         # side streams under the flow kernels of wavefront k (materials.WavefrontPipeline); every wavefront still does all
         # five stages inside the timed region ($BSDFD_BENCH_MIXED_SERIAL=1: the stages one after the other on one stream)
@@ -760,6 +763,36 @@ def worker(a):
                          "sample_pdf_split_basis": "the timed region's own launches by kind (bsdfd_profile_read_op)",
                          "sample_Msamples_per_s": n_local / (split["sample"] * 1e-3) / 1e6 if split.get("sample") else None,
                          "pdf_Msamples_per_s": n_local / (split["pdf"] * 1e-3) / 1e6 if split.get("pdf") else None})
+            # the per-query context in both call orders (outside the timed region): sample() fills / pdf() reads — the bench's
+            # pass — and pdf() fills / sample() reads — the order of Mitsuba's path integrator (eval_pdf for the emitter
+            # sample first, rendering/brdf_measured_disk.py:126, then sample, :59) — next to the pair without a context
+            if wl.ctx is not None:
+                orders = {}
+                for order in ("sample_then_pdf", "pdf_then_sample", "no_context"):
+                    def pair(k):
+                        kw_s = dict(T=wl.T, variant=wl.variant, seed=300 + k, out=(wl.wo[1], wl.pdf_s[1]))
+                        kw_p = dict(T=wl.T, variant=wl.variant, out=wl.pdf_p[1])
+                        if order == "sample_then_pdf":
+                            wl.smp.plugin_sample(wl.wi, None, ctx_out=wl.ctx, **kw_s)
+                            wl.smp.plugin_pdf(wl.wi, wl.wo[0], ctx_in=wl.ctx, **kw_p)
+                        elif order == "pdf_then_sample":
+                            wl.smp.plugin_pdf(wl.wi, wl.wo[0], ctx_out=wl.ctx, **kw_p)
+                            wl.smp.plugin_sample(wl.wi, None, ctx_in=wl.ctx, **kw_s)
+                        else:
+                            wl.smp.plugin_sample(wl.wi, None, **kw_s)
+                            wl.smp.plugin_pdf(wl.wi, wl.wo[0], **kw_p)
+                    for k in range(6):
+                        pair(k)
+                    torch.cuda.synchronize()
+                    profiling(wl, True)
+                    for k in range(24):
+                        pair(6 + k)
+                    _, ms = profile_read(wl)
+                    profiling(wl, False)
+                    orders[order] = ms / 24
+                roof["flow_launches_after_timed_region"] += 3 * 60
+                roof["context_pair_ms"] = dict(orders, basis="kernel time of one sample() + pdf() pair on the same wavefront, 24 pairs "
+                                               "after 6 warm-up pairs, outside the timed region")
             # issue-bound view: measured SIMD cycles per (16-query tile x Euler step) vs the instruction-issue model
             try:
                 probe_mhz = _lib.shader_clock_mhz()

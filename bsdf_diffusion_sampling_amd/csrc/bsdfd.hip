@@ -257,6 +257,28 @@ __device__ __forceinline__ float fast_acos(float x) {
     return x < 0.0f ? 3.14159265358979323846f - r : r;
 }
 
+// cart_to_spher of the spherical plugins (rendering/brdf_measured_spherical.py:35-39): theta = acos(z / (r + 1e-8)), phi = atan2(y, x).
+// Evaluated as written, fp32 loses theta near the pole: the quotient is rounded to a multiple of 6e-8 and acos amplifies that by
+// 1 / sin(theta) — up to 6.5e-5 rad on the golden fixtures, which the encoder's 2^4 and the flow turn into 1.0e-4 (p99) of pdf error
+// on chm_orange: the reference's own fp32-vs-fp64 distance at plugin level.  The SAME angle in a well-conditioned form: with
+// r' = r + eps, cos(theta) = z / r' and sin(theta) = sqrt(r'^2 - z^2) / r' = sqrt(x^2 + y^2 + 2 r eps + eps^2) / r' (a sum of
+// non-negative terms), so theta = atan2(sqrt(x^2 + y^2 + 2 r eps + eps^2), z) — identical in real arithmetic, eps included (at
+// the pole both give sqrt(2 eps)), 1.5e-7 rad from the fp64 value on the same fixtures.  `ref_pole`: where the reference's fp32
+// quotient is not inside (-1, 1) its theta is 0, pi or NaN and its sin(theta) > 5e-5 guard zeroes the density: pdf() keeps that
+// decision (rendering/brdf_measured_spherical.py:134).
+__device__ __forceinline__ void cart_to_spher(float x, float y, float z, float& theta, float& phi, bool& ref_pole) {
+    const float eps = 1e-8f;
+    const float s2 = x * x + y * y;
+    const float r = sqrtf(s2 + z * z);
+#ifdef BSDFD_TOOLS_ACOS_AS_WRITTEN   // (tools/ab_build.sh: the reference's form, for within-run A/B of time and accuracy)
+    theta = acosf(z / (r + eps));
+#else
+    theta = atan2f(sqrtf(s2 + (2.0f * r * eps + eps * eps)), z);
+#endif
+    phi = atan2f(y, x);
+    ref_pole = !(fabsf(z / (r + eps)) < 1.0f);
+}
+
 // log I0(kappa): the two polynomials of torch.distributions.von_mises._log_modified_bessel_fn
 // (torch 2.10; call site rendering/utils/model.py:314), split at 3.75.
 __device__ __forceinline__ float log_i0(float k) {
@@ -480,6 +502,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
         // ---------------- inputs: condition (y0,y1) and, for pdf, the outgoing point -------------
         float y0 = 0.f, y1 = 0.f, wi_z = 1.0f;
         float xs0 = 0.f, xs1 = 0.f, wo_z = 1.0f, wo_sin = 1.0f;  // pdf: the point the reverse flow starts from
+        bool wo_pole = false;                                    // spherical plugin pdf: the reference's sin(theta_o) guard fires
         float xi0 = 0.f, xi1 = 0.f;                              // sample: injected x0 (if any)
         // per-query context: a launch that is handed the context an earlier sample / pdf launch wrote for the SAME wi array
         // skips everything below that depends on wi alone (cart_to_spher(wi), encoding, conditioning term, base net)
@@ -491,9 +514,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
             if (DOMAIN == BSDFD_DOMAIN_DISK) {
                 xs0 = ox; xs1 = oy;
             } else {
-                const float r = sqrtf(ox * ox + oy * oy + oz * oz);
-                xs0 = acosf(oz / (r + 1e-8f));
-                xs1 = atan2f(oy, ox);
+                cart_to_spher(ox, oy, oz, xs0, xs1, wo_pole);
             }
         };
         if (p.io == IO_OPERATOR) {
@@ -508,10 +529,9 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
             wi_z = wz;
             if (DOMAIN == BSDFD_DOMAIN_DISK) {
                 y0 = wx; y1 = wy;  // rendering/brdf_measured_disk.py:66-67
-            } else if (!have_ctx) {  // cart_to_spher, rendering/brdf_measured_spherical.py:35-39
-                const float r = sqrtf(wx * wx + wy * wy + wz * wz);
-                y0 = acosf(wz / (r + 1e-8f));
-                y1 = atan2f(wy, wx);
+            } else if (!have_ctx) {  // rendering/brdf_measured_spherical.py:35-39
+                bool unused;
+                cart_to_spher(wx, wy, wz, y0, y1, unused);
             }
             if (!FUSED && p.op == OP_PDF) load_dir(p.in_b);  // (the fused kernel loads wl at its phase switch: 4 registers less across phase 1)
             if ((FUSED || p.op != OP_PDF) && p.in_b != nullptr) {  // injected base sample
@@ -1377,9 +1397,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
             } else {
                 const float inv = fminf(fmaxf(1.0f / wo_sin, 1.0f), 3.402823466e+38f);
                 if (p.io == IO_PLUGIN) {  // rendering/brdf_measured_spherical.py:122-137
-                    float s0_, c0_;
-                    sincos_enc(xs0, s0_, c0_);
-                    if (!(s0_ > 0.00005f)) pdf = 0.0f;
+                    if (wo_pole) pdf = 0.0f;   // sin(theta_o) > 0.00005 as the reference's fp32 cart_to_spher decides it
                     pdf_sa = (wi_z > 0.0f && wo_z > 0.0f) ? pdf * inv : 0.0f;
                 } else {                  // rendering/bsdf_myresult.py:115-133
                     pdf_sa = pdf * inv;

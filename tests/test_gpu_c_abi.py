@@ -58,7 +58,9 @@ def test_profile_totals_by_kind_of_launch():
     g, fw = load_case("aniso_miro_7_rgb_disk")
     dev = torch.device("cuda", 0)
     s = FlowSampler(fw)
-    wi = torch.from_numpy(np.tile(g["wi"], (32, 1))).to(dev)
+    v = np.random.default_rng(5).normal(size=(1 << 16, 3)).astype(np.float32)
+    v[:, 2] = np.abs(v[:, 2])
+    wi = torch.from_numpy(v / np.linalg.norm(v, axis=1, keepdims=True)).to(dev)
     wo, p = s.plugin_sample(wi, None, T=4, seed=1)
     s.set_profiling(True)
     for k in range(3):

@@ -84,8 +84,8 @@ def test_config4_128Mi_mixed_queries_in_8_virtual_shards():
         err_wo, noise_wo = np.abs(wo_s.cpu().numpy() - wo_o), np.abs(wo_32.astype(np.float64) - wo_o)
         rel = np.abs(pdf_s.cpu().numpy() - pdf_o)[sel] / np.abs(pdf_o[sel])
         noise = np.abs(pdf_32.astype(np.float64) - pdf_o)[sel] / np.abs(pdf_o[sel])
-        assert np.percentile(err_wo, 99) <= 1e-5 and err_wo.max() <= max(1e-4, 2 * noise_wo.max()), tab.stems[m]
-        assert np.percentile(rel, 99) <= max(1e-4, 2 * np.percentile(noise, 99)), (tab.stems[m], np.percentile(rel, 99))
+        assert np.percentile(err_wo, 99) <= 1e-5 and err_wo.max() <= 1e-4, tab.stems[m]
+        assert np.percentile(rel, 99) <= 1e-4, (tab.stems[m], np.percentile(rel, 99), np.percentile(noise, 99))
         checked += 512
     assert checked == 4096
     torch.cuda.synchronize()

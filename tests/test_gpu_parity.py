@@ -228,7 +228,9 @@ def test_plugin_spherical_sample_and_pdf(stem, full):
     s = _sampler(fw, "split3")
     orc = O.Oracle(fw)
     variant = _lib.PLUGIN_FULLSPHERE if full else _lib.PLUGIN_MEASURED
-    th = np.clip(g["wi"][:, 0].astype(np.float64), 0.05, None)  # acos() is ill-conditioned at the pole
+    # (down to 1e-3 rad of the pole: the kernel evaluates cart_to_spher in its well-conditioned form, csrc/bsdfd.hip; the fp32
+    #  restatement below shows what acos() as written loses there)
+    th = np.clip(g["wi"][:, 0].astype(np.float64), 0.001, None)
     wi3 = _dir(th, g["wi"][:, 1].astype(np.float64))
     wo, pdf = s.plugin_sample(_t(wi3), _t(g["x0"]), T=8, variant=variant)
     wo, pdf = wo.cpu().numpy(), pdf.cpu().numpy()
@@ -238,7 +240,7 @@ def test_plugin_spherical_sample_and_pdf(stem, full):
     orc32 = O.Oracle(fw, np.float32)
     wo_32, pdf_32 = O.plugin_sample_spherical(orc32, wi3, g["x0"], T=8, full_sphere=full)
     err_wo, noise_wo = np.abs(wo - wo_o), np.abs(wo_32.astype(np.float64) - wo_o)
-    assert np.percentile(err_wo, 99) <= 1e-5 and err_wo.max() <= max(1e-4, 2 * noise_wo.max())
+    assert np.percentile(err_wo, 99) <= 1e-5 and err_wo.max() <= 1e-4
     assert np.allclose((wo ** 2).sum(1), 1.0, atol=1e-5)
     if not full:
         assert np.all(pdf[wo_o[:, 2] < -1e-4] == 0)
@@ -247,7 +249,7 @@ def test_plugin_spherical_sample_and_pdf(stem, full):
     e, n32 = _rel(pdf, pdf_o)[ok], _rel(pdf_32.astype(np.float64), pdf_o)[ok]
     _record(f"plugin_spherical_sample[{stem}]", wo_p99=np.percentile(err_wo, 99), wo_max=err_wo.max(), pdf_median=np.median(e),
             pdf_p99=np.percentile(e, 99), fp32_oracle_wo_max=noise_wo.max(), fp32_oracle_pdf_p99=np.percentile(n32, 99))
-    assert np.percentile(e, 99) <= max(1e-4, 2 * np.percentile(n32, 99))
+    assert np.percentile(e, 99) <= 1e-4
     # pdf() on fresh directions
     tho = np.clip(g["pdf_wo_b"][:, 0].astype(np.float64), 0.05, 3.09)
     wo3 = _dir(tho, g["pdf_wo_b"][:, 1].astype(np.float64))
@@ -258,7 +260,7 @@ def test_plugin_spherical_sample_and_pdf(stem, full):
     ok = _resolved(p_o, acc)
     e, n32 = _rel(p, p_o)[ok], _rel(p_32.astype(np.float64), p_o)[ok]
     _record(f"plugin_spherical_pdf[{stem}]", pdf_median=np.median(e), pdf_p99=np.percentile(e, 99), fp32_oracle_pdf_p99=np.percentile(n32, 99))
-    assert np.percentile(e, 99) <= max(1e-4, 2 * np.percentile(n32, 99))
+    assert np.percentile(e, 99) <= 1e-4
     if not full:
         assert np.all(p[wo3[:, 2] <= 0] == 0)
 
@@ -685,9 +687,10 @@ def test_plugin_level_vs_reference_plugin_goldens(stem):
     """Plugin-level parity against tests/golden/<stem>_plugin.npz: the reference's own operators followed by the plugins'
     tensor ops (rendering/brdf_measured_disk.py:59-82,112-124, brdf_measured_spherical.py:35-39,69-91,122-137,
     bsdf_myresult.py:59-84,115-133), in fp32 as the plugins run them and in fp64.
-    Bounds (north_star: 1e-4 on directions and pdfs): directions p99 <= 1e-5 and max <= max(1e-4, 2 x the fp32 reference's
-    own max error against its fp64 run); pdf p99 <= max(1e-4, 2 x the fp32 reference's own p99 error) — the reference's
-    fp32 acos / atan2 / sincos chain alone reaches 1.4e-4 on chm_orange (measured in the fixture, recorded below)."""
+    Bounds (north_star: 1e-4 on directions and pdfs, against the fp64 run): directions p99 <= 1e-5 and max <= 1e-4; pdf p99 <=
+    1e-4 — FIXED bounds since round 4: the reference's own fp32 run is 1.4e-4 / 2.1e-4 away from its fp64 run on chm_orange
+    (acos as written near the pole; recorded below as ref32_*), the kernel evaluates the same angle in a well-conditioned
+    form (csrc/bsdfd.hip, cart_to_spher) and stays below 7e-5 / 1e-5 on every fixture."""
     from bsdf_diffusion_sampling_amd import _lib
     from conftest import GOLDEN
     import os
@@ -709,8 +712,8 @@ def test_plugin_level_vs_reference_plugin_goldens(stem):
             pdf_p99=np.percentile(err_pdf, 99), ref32_wo_p99=np.percentile(noise_wo, 99), ref32_wo_max=noise_wo.max(),
             ref32_pdf_p99=np.percentile(noise_pdf, 99))
     assert np.percentile(err_wo, 99) <= 1e-5
-    assert err_wo.max() <= max(1e-4, 2 * noise_wo.max())
-    assert np.percentile(err_pdf, 99) <= max(1e-4, 2 * np.percentile(noise_pdf, 99))
+    assert err_wo.max() <= 1e-4
+    assert np.percentile(err_pdf, 99) <= 1e-4
     # guards: rows the reference zeroes are zero here (rows that sit within fp32 noise of a threshold excepted)
     z_ref, z_got = p["sample_pdf_sa"] == 0, pdf == 0
     decided = (ref_pdf == 0) | (np.abs(ref_pdf) > 1e-30)   # (a density that underflows fp32 may be 0 or a subnormal on either side)
@@ -731,7 +734,7 @@ def test_plugin_level_vs_reference_plugin_goldens(stem):
         e, n32 = _rel(got, want)[okp], _rel(p[key].astype(np.float64), want)[okp]
         _record(f"plugin_pdf[{stem}:{key}]", pdf_median=np.median(e), pdf_p99=np.percentile(e, 99), ref32_pdf_p99=np.percentile(n32, 99),
                 vs_ref32_p99=np.percentile(_rel(got, p[key].astype(np.float64))[okp], 99))
-        assert np.percentile(e, 99) <= max(1e-4, 2 * np.percentile(n32, 99))
+        assert np.percentile(e, 99) <= 1e-4
         assert (((p[key] == 0) != (got == 0)) & ((want == 0) | (np.abs(want) > 1e-30))).sum() <= 2
     if not full:
         got = s.plugin_pdf(_t(p["pdf_wi3"]), _t(p["pdf_wo3"]), T=T, variant=variant).cpu().numpy()
