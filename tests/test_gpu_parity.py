@@ -265,6 +265,48 @@ def test_plugin_spherical_sample_and_pdf(stem, full):
         assert np.all(p[wo3[:, 2] <= 0] == 0)
 
 
+def test_spherical_directions_at_and_near_the_pole():
+    """cart_to_spher (rendering/brdf_measured_spherical.py:35-39) for wi and wo within 1e-6 .. 1e-2 rad of the normal, and exactly
+    on it: acos(z / (r + 1e-8)) as written loses the angle there in fp32 (the quotient rounds to 1: theta = 0, or to the next
+    float: 3.5e-4); the kernel's form of the same angle follows the fp64 oracle to the usual bounds.  pdf() keeps the
+    reference's guard decision on the axis (fp32 theta_o = 0 -> sin(theta_o) > 5e-5 fails -> 0) for the measured variant."""
+    from bsdf_diffusion_sampling_amd import _lib
+    g, fw = load_case("chm_orange_rgb_spherical")
+    s = _sampler(fw, "split3")
+    orc, orc32 = O.Oracle(fw), O.Oracle(fw, np.float32)
+    rng = np.random.default_rng(11)
+    n = g["x0"].shape[0]
+    th = 10.0 ** rng.uniform(-6, -2, n)
+    th[:4] = 0.0                                                     # exactly the normal
+    wi3 = _dir(th, rng.uniform(-np.pi, np.pi, n))
+    wo, pdf = s.plugin_sample(_t(wi3), _t(g["x0"]), T=8)
+    wo, pdf = wo.cpu().numpy(), pdf.cpu().numpy()
+    wo_o, pdf_o = O.plugin_sample_spherical(orc, wi3.astype(np.float64), g["x0"], T=8)
+    wo_32, pdf_32 = O.plugin_sample_spherical(orc32, wi3, g["x0"], T=8)
+    _, acc = orc.flow(g["x0"], O.cart_to_spher(wi3.astype(np.float64)), 8, reverse=False)
+    ok = _resolved(pdf_o, acc)
+    e, n32 = _rel(pdf, pdf_o)[ok], _rel(pdf_32.astype(np.float64), pdf_o)[ok]
+    _record("plugin_spherical_sample_near_pole[chm_orange_rgb_spherical]", wo_max=np.abs(wo - wo_o).max(), pdf_p99=np.percentile(e, 99),
+            fp32_oracle_wo_max=np.abs(wo_32 - wo_o).max(), fp32_oracle_pdf_p99=np.percentile(n32, 99))
+    assert np.isfinite(wo).all() and np.isfinite(pdf).all()
+    assert np.abs(wo - wo_o).max() <= 1e-4 and np.percentile(e, 99) <= 1e-4
+    # pdf(): wo near the pole (the 1 / sin(theta_o) Jacobian is clamped as in the reference), wi ordinary
+    wi_b = _dir(np.clip(g["wi"][:, 0].astype(np.float64), 0.05, 1.5), g["wi"][:, 1].astype(np.float64))
+    tho = 10.0 ** rng.uniform(-3.3, -2, n)
+    wo3 = _dir(tho, rng.uniform(-np.pi, np.pi, n))
+    p = s.plugin_pdf(_t(wi_b), _t(wo3), T=8).cpu().numpy()
+    p_o = O.plugin_pdf_spherical(orc, wi_b.astype(np.float64), wo3.astype(np.float64), T=8)
+    _, acc = orc.flow(O.cart_to_spher(wo3.astype(np.float64)), O.cart_to_spher(wi_b.astype(np.float64)), 8, reverse=True)
+    ok = _resolved(p_o, acc)
+    e = _rel(p, p_o)[ok]
+    _record("plugin_spherical_pdf_near_pole[chm_orange_rgb_spherical]", pdf_p99=np.percentile(e, 99))
+    assert np.percentile(e, 99) <= 1e-4
+    axis = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (8, 1))
+    assert np.all(s.plugin_pdf(_t(wi_b[:8]), _t(axis), T=8).cpu().numpy() == 0)
+    pf = s.plugin_pdf(_t(wi_b[:8]), _t(axis), T=8, variant=_lib.PLUGIN_FULLSPHERE).cpu().numpy()
+    assert not np.isnan(pf).any() and np.all(pf > 0)   # (density x the clamped 1 / sin(theta_o) = 3.4e38)
+
+
 @pytest.mark.parametrize("stem", ["chm_orange_rgb_disk", "aniso_miro_7_rgb_spherical", "bsdf_3_spherical"])
 def test_in_kernel_rng_statistics(stem):
     """x0 drawn in-kernel (Philox): only statistical parity with torch's RNG stream is
