@@ -50,7 +50,7 @@ SECONDARY = ("disk_1Mi_T4", "spherical_16Mi_T8", "mixed_16Mi", "teacher_64x6_4Mi
 # the per-query context pays while it round-trips through the 256 MiB Infinity Cache and stops paying once it streams through
 # HBM (plugin_base.NeuralBSDFCore applies the same gate): wavefronts whose record is larger run without it
 CONTEXT_MAX_BYTES = 192 << 20
-USE_CONTEXT = os.environ.get("BSDFD_BENCH_CONTEXT", "1") != "0"  # --context off: plain sample() / pdf() calls
+USE_CONTEXT = os.environ.get("BSDFD_BENCH_CONTEXT", "0") != "0"  # --context on: sample() hands the per-query context to pdf()
 
 
 def make_wi(domain, n, seed, device):
@@ -738,7 +738,9 @@ def worker(a):
         flops_launch = wl.flops_per_pass / wl.launches_per_pass
         achieved = wl.flops_per_pass * R * a.steps / (kern_ms * 1e-3) / 1e12
         pmc_entry, pmc_prov = profile_lookup("pmc_latest.json", a.workload)
-        traffic = (pmc_entry or {}).get("hbm_bytes_per_launch")
+        ctx_on = getattr(wl, "ctx", None) is not None
+        # (the committed PMC passes are those of the DEFAULT command, i.e. without the per-query context: withheld under --context on)
+        traffic = None if ctx_on else (pmc_entry or {}).get("hbm_bytes_per_launch")
         algo_bytes = 28 * n_local
         roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": traffic,
@@ -746,9 +748,10 @@ def worker(a):
                                                      "condensed by tools/summarize_profile.py; looked up, not re-measured in this run"),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
-                "traffic_note": "with the per-query context on, a sample launch also WRITES and a pdf launch also READS the context "
-                                "(144 B/query for the 32-wide nets) = 5.1x the 28 algorithmic bytes, by design: it replaces the "
-                                "prologue's recomputation; HBM stays below 5 % of its bandwidth",
+                "traffic_note": ("--context on: a sample launch also WRITES and a pdf launch also READS the per-query context (144 B/query "
+                                 "for the 32-wide nets, 5.1x the 28 algorithmic bytes; profiles/r04_ab/: 166 MB per launch); the committed "
+                                 "PMC passes are those of the default command and are withheld here") if ctx_on else
+                                "wi / wo / pdf rows read and written once (28 B per query); the per-query context is off by default",
                 "kernel": "flow_kernel", "launches": n_launch, "avg_launch_ms": avg_ms, "shader_clock_mhz": kern_mhz,
                 "algorithmic_flop_per_launch": flops_launch, "queries_per_launch": n_local,
                 "kernel_Msamples_per_s": wl.query_launches_per_pass * R * a.steps / (kern_ms * 1e-3) / 1e6,
@@ -766,33 +769,41 @@ def worker(a):
             # the per-query context in both call orders (outside the timed region): sample() fills / pdf() reads — the bench's
             # pass — and pdf() fills / sample() reads — the order of Mitsuba's path integrator (eval_pdf for the emitter
             # sample first, rendering/brdf_measured_disk.py:126, then sample, :59) — next to the pair without a context
-            if wl.ctx is not None:
-                orders = {}
-                for order in ("sample_then_pdf", "pdf_then_sample", "no_context"):
-                    def pair(k):
-                        kw_s = dict(T=wl.T, variant=wl.variant, seed=300 + k, out=(wl.wo[1], wl.pdf_s[1]))
-                        kw_p = dict(T=wl.T, variant=wl.variant, out=wl.pdf_p[1])
-                        if order == "sample_then_pdf":
-                            wl.smp.plugin_sample(wl.wi, None, ctx_out=wl.ctx, **kw_s)
-                            wl.smp.plugin_pdf(wl.wi, wl.wo[0], ctx_in=wl.ctx, **kw_p)
-                        elif order == "pdf_then_sample":
-                            wl.smp.plugin_pdf(wl.wi, wl.wo[0], ctx_out=wl.ctx, **kw_p)
-                            wl.smp.plugin_sample(wl.wi, None, ctx_in=wl.ctx, **kw_s)
-                        else:
-                            wl.smp.plugin_sample(wl.wi, None, **kw_s)
-                            wl.smp.plugin_pdf(wl.wi, wl.wo[0], **kw_p)
-                    for k in range(6):
-                        pair(k)
-                    torch.cuda.synchronize()
-                    profiling(wl, True)
-                    for k in range(24):
-                        pair(6 + k)
-                    _, ms = profile_read(wl)
-                    profiling(wl, False)
-                    orders[order] = ms / 24
-                roof["flow_launches_after_timed_region"] += 3 * 60
-                roof["context_pair_ms"] = dict(orders, basis="kernel time of one sample() + pdf() pair on the same wavefront, 24 pairs "
-                                               "after 6 warm-up pairs, outside the timed region")
+            pair_ctx = wl.ctx if wl.ctx is not None else (wl.smp.new_context(n_local) if wl.smp.context_floats(n_local) * 4 <= CONTEXT_MAX_BYTES else None)
+            if pair_ctx is not None:
+                def pair(order, k):
+                    kw_s = dict(T=wl.T, variant=wl.variant, seed=300 + k, out=(wl.wo[1], wl.pdf_s[1]))
+                    kw_p = dict(T=wl.T, variant=wl.variant, out=wl.pdf_p[1])
+                    if order == "sample_then_pdf":
+                        wl.smp.plugin_sample(wl.wi, None, ctx_out=pair_ctx, **kw_s)
+                        wl.smp.plugin_pdf(wl.wi, wl.wo[0], ctx_in=pair_ctx, **kw_p)
+                    elif order == "pdf_then_sample":
+                        wl.smp.plugin_pdf(wl.wi, wl.wo[0], ctx_out=pair_ctx, **kw_p)
+                        wl.smp.plugin_sample(wl.wi, None, ctx_in=pair_ctx, **kw_s)
+                    else:
+                        wl.smp.plugin_sample(wl.wi, None, **kw_s)
+                        wl.smp.plugin_pdf(wl.wi, wl.wo[0], **kw_p)
+                # the three forms INTERLEAVED in rounds of 8 pairs (the chip's clock drifts for tens of ms after the host-side
+                # pause behind the timed region: one form after the other measures the drift, not the forms)
+                ORDERS, ROUNDS, PAIRS = ("sample_then_pdf", "pdf_then_sample", "no_context"), 4, 8
+                for k in range(24):
+                    pair(ORDERS[k % 3], k)
+                torch.cuda.synchronize()
+                profiling(wl, True)
+                totals, seen = dict.fromkeys(ORDERS, 0.0), 0.0
+                for rnd in range(ROUNDS):
+                    for order in ORDERS:
+                        for k in range(PAIRS):
+                            pair(order, 24 + rnd * PAIRS + k)
+                        _, ms = profile_read(wl)
+                        totals[order] += ms - seen
+                        seen = ms
+                profiling(wl, False)
+                roof["flow_launches_after_timed_region"] += 2 * (24 + 3 * ROUNDS * PAIRS)
+                roof["context_pair_ms"] = dict({o: totals[o] / (ROUNDS * PAIRS) for o in ORDERS},
+                                               basis=f"kernel time of one sample() + pdf() pair on the same wavefront; the three forms "
+                                                     f"interleaved, {ROUNDS} rounds x {PAIRS} pairs each, outside the timed region")
+                pair_ctx = None   # (frees the 144 MiB record before the secondary workloads allocate)
             # issue-bound view: measured SIMD cycles per (16-query tile x Euler step) vs the instruction-issue model
             try:
                 probe_mhz = _lib.shader_clock_mhz()
@@ -904,7 +915,8 @@ def main():
     ap.add_argument("--passes-per-step", type=int, default=0,
                     help="wavefronts per step (0 = sized at setup so that the timed region lasts >= 0.5 s)")
     ap.add_argument("--context", default=None, choices=["on", "off"],
-                    help="per-query context hand-over from sample() to pdf() of the same wavefront (default on)")
+                    help="per-query context hand-over from sample() to pdf() of the same wavefront (default off: it buys 1-2 %% of a pair "
+                         "for 5x the HBM traffic; roofline.context_pair_ms reports both forms either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--settle-ms", type=float, default=150.0,

@@ -93,10 +93,12 @@ class NeuralBSDFCore:
         # intersections (rendering/brdf_measured_disk.py:112,59; Mitsuba's path integrator in the order eval_pdf() -> sample()),
         # so whichever call sees an si.wi first also writes what depends on wi alone and the later ones read it.  Keyed on the
         # identity + version of the wi tensor and on the sampler handle; 144 B per query (ONE reused buffer per plugin
-        # instance).  Capped at 192 MiB by default: the record pays while it round-trips through the 256 MiB Infinity Cache
-        # (1 Mi queries: -2.4 % of a sample()+pdf() pair) and stops paying once it streams through HBM (16 Mi spherical
-        # queries, 2.4 GB: -1 %), so larger wavefronts run without it.
-        self.context_cache = bool(get("context_cache", True))
+        # instance).  OPT-IN since round 4 (props["context_cache"] = True): with the cheaper prologue of that round a
+        # sample()+pdf() pair of a 1 Mi-query wavefront gains 1.1 % (disk, T = 8), 2.2 % (spherical) and nothing measurable at the
+        # disk plugin's default T = 4 (tools/ctx_pair.py, profiles/r04_ab/ctx_pair.txt) for 144 B of device memory per query and
+        # 5x the HBM traffic.  Capped at 192 MiB: above that the record streams through HBM instead of the 256 MiB Infinity
+        # Cache and stops paying altogether.
+        self.context_cache = bool(get("context_cache", False))
         self.context_cache_max_bytes = int(get("context_cache_max_bytes", 192 << 20))
         # (key, wi tensor, buffer) of the last launch that FILLED the buffer successfully.  The entry keeps a reference to the
         # tensor it was filled for (12 B per query next to the 144 B of the record): its storage cannot be freed and handed to

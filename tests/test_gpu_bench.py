@@ -57,7 +57,7 @@ def test_bench_line_single_gpu_with_secondary_and_cpu_baseline():
     r = d["roofline"]   # the sample / pdf split is the timed region's own: it averages to the judged launch time
     assert abs((r["sample_launch_ms"] + r["pdf_launch_ms"]) / 2 - r["avg_launch_ms"]) < 1e-3 * r["avg_launch_ms"], r
     cp = r["context_pair_ms"]   # the context pays in either call order
-    assert 0 < cp["sample_then_pdf"] < cp["no_context"] * 1.01 and 0 < cp["pdf_then_sample"] < cp["no_context"] * 1.01, cp
+    assert 0 < cp["sample_then_pdf"] < cp["no_context"] * 1.02 and 0 < cp["pdf_then_sample"] < cp["no_context"] * 1.02, cp
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["all_cores"]["cores"] >= cb["cores"]
     ac = cb["all_cores"]  # a child process with a time budget: a figure, or an honest "did not finish" with an upper bound

@@ -647,8 +647,9 @@ def test_plugin_core_context_cache():
     keyed on the identity and version of si.wi; whichever call comes first fills it."""
     from bsdf_diffusion_sampling_amd.brdf_measured_spherical import MyBSDF
     from bsdf_diffusion_sampling_amd.plugin_base import SurfaceInteraction
-    plug = MyBSDF({"filename": "chm_orange_rgb", "measured": False})
-    off = MyBSDF({"filename": "chm_orange_rgb", "measured": False, "context_cache": False})
+    plug = MyBSDF({"filename": "chm_orange_rgb", "measured": False, "context_cache": True})   # opt-in since round 4
+    off = MyBSDF({"filename": "chm_orange_rgb", "measured": False})
+    assert off.context_cache is False
     rng = np.random.default_rng(3)
     z, ph = rng.uniform(0.1, 1.0, size=5000), rng.uniform(0, 2 * np.pi, size=5000)
     wi = _t(np.stack([np.sqrt(1 - z * z) * np.cos(ph), np.sqrt(1 - z * z) * np.sin(ph), z], 1))
@@ -710,11 +711,11 @@ def test_plugin_core_context_cache():
         torch.cuda.synchronize()
         assert torch.equal(pk, p_hit) and torch.equal(a_.wo, bs.wo)
     # over the cap: no cache, same results
-    small = MyBSDF({"filename": "chm_orange_rgb", "measured": False, "context_cache_max_bytes": 1024})
+    small = MyBSDF({"filename": "chm_orange_rgb", "measured": False, "context_cache": True, "context_cache_max_bytes": 1024})
     small.sample(None, si, seed=5)
     assert small._ctx is None and torch.equal(small.pdf(None, si, wl), p_hit)
     # a host that never presents the same tensor twice: filling stops after `context_cache_patience` unread fills
-    lone = MyBSDF({"filename": "chm_orange_rgb", "measured": False})
+    lone = MyBSDF({"filename": "chm_orange_rgb", "measured": False, "context_cache": True})
     for k in range(8):
         lone.sample(None, SurfaceInteraction(wi.clone()), seed=5)
     assert lone._ctx_unread_fills == lone.context_cache_patience and lone._ctx is None
