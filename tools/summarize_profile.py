@@ -27,11 +27,23 @@ def main():
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if "flow_kernel" in r["Kernel_Name"]:
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                agg[r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
                 meta = {k: r[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
                                           "SGPR_Count", "Scratch_Size") if k in r}
+        # the counters of the TIMED REGION's launches only, as for the trace below: behind it bench.py issues launches of other
+        # kinds (the context pair in both orders, the T / 2T pair of the issue-bound entry) — the pass's own JSON line says how many
+        n_timed = n_after = None
+        try:
+            line = json.loads([l for l in open(os.path.dirname(f) + ".log") if l.startswith("{")][-1])
+            n_timed = int(line["roofline"]["launches"])
+            n_after = int(line["roofline"].get("flow_launches_after_timed_region", 0))
+        except Exception:
+            pass
         for k, v in agg.items():
-            pmc[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
+            v = [x for _, x in sorted(v)]
+            sel = v[len(v) - n_after - n_timed:len(v) - n_after] if n_timed and len(v) >= n_timed + n_after else v
+            pmc[k] = {"launches": len(sel), "mean_per_launch": sum(sel) / len(sel),
+                      "of": "the timed region's launches" if sel is not v else "every flow-kernel launch of the pass"}
     out = {"tag": tag, "workload": workload, "kernel": meta, "counters": pmc}
     # kernel duration from the trace
     for r in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))):
