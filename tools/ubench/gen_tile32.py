@@ -52,13 +52,16 @@ v_permlane16_swap_b32 v_cvt_pk_f16_f32 v_cvt_pk_f16_f32 v_cvt_pk_f16_f32 v_sub_f
 v_mfma_f32_16x16x32_f16 v_cndmask_b32 v_mul_f32 s_nop_2 v_pk_add_f32 s_nop_0 v_pk_fma_f32""".split()
 
 NA, NP, NH, NF = 32, 16, 8, 8   # pools: f32 scalars, f32 pairs, packed-f16 words, weight fragments (T16 uses 24 / 12 of a / p)
+# ("t16w4": the T16 stream with pools small enough for 128 VGPRs, i.e. 4 waves/SIMD - what a register diet could reach at best)
 
 
 class Gen:
     def __init__(self, variant):
         self.v = variant           # "t16", "t32", "valu", "mfma"
         self.ia = self.ip = self.ih = self.ifr = self.im = 0
-        self.na, self.np_ = (NA, NP) if variant == "t32" else (24, 12)
+        self.na, self.np_ = (NA, NP) if variant == "t32" else ((20, 10) if variant == "t16w4" else (24, 12))
+        self.nf = 6 if variant == "t16w4" else NF
+        self.nc = 4 if variant == "t16w4" else 6
         self.out = []
 
     def a(self):
@@ -122,23 +125,23 @@ class Gen:
                     self.emit('asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");')
             elif op == "ds_read_b128":
                 if self.v != "valu":
-                    self.ifr = (self.ifr + 1) % NF
+                    self.ifr = (self.ifr + 1) % self.nf
                     self.emit('asm volatile("ds_read_b128 %%0, %%1 offset:%d" : "=v"(f[%d]) : "v"(lds_base) : "memory");' % (1024 * self.ifr, self.ifr))
             elif op.startswith("v_mfma"):
                 if self.v == "valu":
                     continue
                 self.im += 1
-                fr, hb = self.im % NF, self.im % 2
+                fr, hb = self.im % self.nf, self.im % 2
                 if op == "v_mfma_f32_16x16x32_f16":
                     if self.v == "t32":
                         self.emit('asm volatile("v_mfma_f32_32x32x16_f16 %%0, %%1, %%2, %%0" : "+v"(C[%d]) : "v"(f[%d]), "v"(hb[%d]));' % ((self.im // 6) % 2, fr, hb))
                     else:
-                        self.emit('asm volatile("v_mfma_f32_16x16x32_f16 %%0, %%1, %%2, %%0" : "+v"(c[%d]) : "v"(f[%d]), "v"(hb[%d]));' % ((self.im // 3) % 6, fr, hb))
+                        self.emit('asm volatile("v_mfma_f32_16x16x32_f16 %%0, %%1, %%2, %%0" : "+v"(c[%d]) : "v"(f[%d]), "v"(hb[%d]));' % ((self.im // 3) % self.nc, fr, hb))
                 else:
                     if self.v == "t32":
                         self.emit('asm volatile("v_mfma_f32_32x32x2_f32 %%0, %%1, %%2, %%0" : "+v"(C[%d]) : "v"(w1[0]), "v"(w1[1]));' % (self.im % 2))
                     else:
-                        self.emit('asm volatile("v_mfma_f32_16x16x4_f32 %%0, %%1, %%2, %%0" : "+v"(c[%d]) : "v"(w1[0]), "v"(w1[1]));' % (self.im % 6))
+                        self.emit('asm volatile("v_mfma_f32_16x16x4_f32 %%0, %%1, %%2, %%0" : "+v"(c[%d]) : "v"(w1[0]), "v"(w1[1]));' % (self.im % self.nc))
             else:
                 if self.v == "mfma":
                     continue
@@ -148,11 +151,11 @@ class Gen:
         return self.out
 
 
-VARIANTS = ["t16", "t32", "valu", "mfma"]
+VARIANTS = ["t16", "t32", "valu", "mfma", "t16w4"]
 src = ['// generated by gen_tile32.py - see its docstring', '#include <hip/hip_runtime.h>', '#include <cstdio>',
        'typedef float f32x2 __attribute__((ext_vector_type(2)));', 'typedef float f32x4 __attribute__((ext_vector_type(4)));',
        'typedef float f32x16 __attribute__((ext_vector_type(16)));', 'typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));',
-       'template <int V> __global__ __launch_bounds__(768) void k(float* out, int iters, long long* cyc) {',
+       'template <int V> __global__ __launch_bounds__(V == 4 ? 1024 : 768) void k(float* out, int iters, long long* cyc) {',
        '    __shared__ f16x8 lds[1024];',
        '    for (int j = threadIdx.x; j < 1024; j += blockDim.x) for (int e = 0; e < 8; ++e) lds[j][e] = (_Float16)(0.001f * (j + e));',
        '    __syncthreads();',
@@ -176,7 +179,7 @@ src += ['    }', '    long long t1 = __builtin_readcyclecounter();',
         '    out[blockIdx.x * blockDim.x + threadIdx.x] = s;',
         '    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicMax((unsigned long long*)cyc, (unsigned long long)(t1 - t0));', '}',
         'template <int V> void run(const char* name, int queries) {', '    static float* out = nullptr; static long long* cyc = nullptr;',
-        '    if (!out) { hipMalloc(&out, 256 * 1024 * 4); hipMalloc(&cyc, 8); }', '    for (int w : {1, 2, 3}) {',
+        '    if (!out) { hipMalloc(&out, 256 * 1024 * 4); hipMalloc(&cyc, 8); }', '    for (int w : {1, 2, 3, 4}) {', '        if (w == 4 && V != 4) continue;',
         '        k<V><<<256, 256 * w>>>(out, 10, cyc); hipDeviceSynchronize(); hipMemset(cyc, 0, 8);',
         '        k<V><<<256, 256 * w>>>(out, 2000, cyc); hipDeviceSynchronize();',
         '        long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);',
@@ -185,5 +188,6 @@ src += ['    }', '    long long t1 = __builtin_readcyclecounter();',
         '    }', '}',
         'int main() {',
         '    run<0>("T16 (16x16x32, as shipped)", 16); run<1>("T32 (32x32x16, VALU doubled)", 32);',
-        '    run<2>("T16 VALU only", 16); run<3>("T16 MFMA + LDS only", 16); return 0;', '}']
+        '    run<2>("T16 VALU only", 16); run<3>("T16 MFMA + LDS only", 16);',
+        '    run<4>("T16, pools for 4 waves/SIMD", 16); return 0;', '}']
 print("\n".join(src))
