@@ -141,19 +141,21 @@ def check_async_lines(lines: List[str], key: str) -> Tuple[int, List[str]]:
     return n_async, bad
 
 
-# Wait states (issued instructions; `s_nop N` counts N + 1) the ISA requires between an MFMA and a later non-MFMA instruction
-# that READS its destination registers (passes + 2) or, for a VALU instruction, OVERWRITES them (passes + 3 for the XDL
-# shapes, passes + 2 for the f32-input ones); a pass = 4 cycles (CDNA3 ISA guide §4.5; LLVM GCNHazardRecognizer::
-# checkMAIVALUHazards; the numbers are the ones hipcc itself pads to in straight-line code).  A branch counts as ONE wait state
-# although a taken branch costs more in practice: the check errs on the safe side.  An intervening MFMA counts as its own number
-# of passes (the matrix pipe runs a wave's MFMAs back to back).  The compiler inserts them — but hipcc 7.2 was caught
-# leaving them out on one path (round 4: an MFMA directly in front of a taken `s_cbranch`, its result read two instructions into
-# the target block: the kernel computed with the stale accumulator), so the build checks.  A load whose DESTINATION is the
-# register is not a hazard (its data returns long after the matrix pipe has drained).
+# Wait states (issued instructions; `s_nop N` counts N + 1) between an MFMA and a later non-MFMA instruction that READS its
+# destination registers or, for a VALU instruction, OVERWRITES them: LLVM's GCNHazardRecognizer::checkMAIVALUHazards for gfx950 -
+# XDL shapes (f16 / bf16 inputs) passes + 4, i.e. 8 for the 4-pass 16x16x32 and 12 for the 8-pass 32x32x16 (what hipcc pads to in
+# straight-line code, and cdna_hip_programming.md §5.7: "8-pass XDL: 12 states"); fp32-input shapes passes + 2.  EVERY intervening
+# instruction - another MFMA included - counts one state, a branch one state (a taken branch costs more in practice: the check errs
+# on the safe side), an `s_nop N` N + 1.  An (empty) inline-asm statement counts what is inside it, i.e. possibly nothing - the
+# compiler counts it as one, which is how a path can end up short.  The compiler inserts the padding - but hipcc 7.2 was caught
+# (round 4) leaving ALL of it out on one path (an MFMA directly in front of a taken `s_cbranch`, its result read two instructions into
+# the target block: the kernel computed with the stale accumulator) and ONE state short on the back edge of every run-time-depth
+# layer loop (csrc/bsdfd.hip, BSDFD_LOOP_HEAD_PAD), so the build checks.  A load whose DESTINATION is the register is not a hazard
+# (its data returns long after the matrix pipe has drained).
 # opcode -> (wait states before a read, before a VALU overwrite)
-MFMA_WAIT = {"v_mfma_f32_16x16x32_f16": (6, 7), "v_mfma_f32_16x16x32_bf16": (6, 7), "v_mfma_f32_16x16x16_f16": (4, 5),
-             "v_mfma_f32_16x16x4_f32": (10, 10), "v_mfma_f32_32x32x16_f16": (10, 11), "v_mfma_f32_32x32x2_f32": (18, 18)}
-MFMA_WAIT_DEFAULT = (18, 19)
+MFMA_WAIT = {"v_mfma_f32_16x16x32_f16": (8, 8), "v_mfma_f32_16x16x32_bf16": (8, 8), "v_mfma_f32_16x16x16_f16": (8, 8),
+             "v_mfma_f32_16x16x4_f32": (10, 10), "v_mfma_f32_32x32x16_f16": (12, 12), "v_mfma_f32_32x32x2_f32": (18, 18)}
+MFMA_WAIT_DEFAULT = (20, 20)
 _LOADS = ("ds_read", "global_load", "scratch_load", "buffer_load", "flat_load", "s_load", "s_buffer_load")
 
 
@@ -221,8 +223,6 @@ def check_mfma_hazards_lines(lines: List[str], key: str) -> Tuple[int, List[str]
                         break
                 if o == "s_nop" and t:
                     w += int(t[0], 0) + 1
-                elif _is_mfma(o):   # the matrix pipe runs the wave's MFMAs back to back: one cannot issue before the previous has had its passes
-                    w += MFMA_WAIT.get(re.sub(r"_(e32|e64)$", "", o), MFMA_WAIT_DEFAULT)[0] - 2
                 else:
                     w += 1
                 j += 1

@@ -215,6 +215,25 @@ __device__ __forceinline__ void lds_read_b128_async_at(f16x8& dst, unsigned lane
 #define BSDFD_WAIT6(after, a, b, c, d, e, f) \
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(after), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : : "memory")
 #endif
+// hipcc's hazard recognizer pads the wait states between an MFMA and the first reader of its result (8 for the 4-pass
+// v_mfma_f32_16x16x32_f16, 10 for the 8-pass fp32 shapes: bsdf_diffusion_sampling_amd/_asmcheck.py), but where the MFMAs sit at the
+// BOTTOM of a run-time loop and the reader at its head it was found ONE state short on the path through the back edge (round 4,
+// every run-time-depth instantiation: 7 of 8 resp. 9 of 10; profiles/r04_ab/mfma_hazard_compiler_gap.txt).  One asm statement at
+// the loop head with two wait states inside that names the loop-carried MFMA results as operands, so that none of their readers
+// can be scheduled in front of it; _asmcheck verifies the shipped assembly with the strict numbers.
+template <int NM, bool JAC>
+__device__ __forceinline__ void loop_head_pad(f32x4 (&z)[NM], f32x4 (&a)[NM], f32x4 (&b)[NM]) {
+    static_assert(NM == 2 || NM == 4, "one operand list per width");
+    if constexpr (NM == 2 && JAC)
+        asm volatile("s_nop 1" : "+v"(z[0]), "+v"(z[1]), "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
+    else if constexpr (NM == 2)
+        asm volatile("s_nop 1" : "+v"(z[0]), "+v"(z[1]));
+    else if constexpr (JAC)
+        asm volatile("s_nop 1" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),
+                     "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    else
+        asm volatile("s_nop 1" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
+}
 union Frag {  // one MFMA B fragment: the lane's 8 K-values of a chunk
     f16x8 v;
     f16x2 p[4];
@@ -711,7 +730,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
             // kernel has no spills and keeps its fragments in registers (the same change costs it 2 %).  The depth-unrolled
             // 64 x 6 kernels could not hold 5 layers of 64-wide fragments in registers at all: same treatment.
             if ((DOMAIN == BSDFD_DOMAIN_SPHERICAL && ((NM == 2 && NH == 4 && JAC) || (NM == 4 && NH == 6))) || (FOLD_L1 && FUSED) || MIM || MIMS)
-                asm volatile("");  // (the fused sample+pdf disk kernel: same treatment; MIM fetches its fragments explicitly)
+                asm volatile("s_nop 0");  // (the fused sample+pdf disk kernel: same treatment; MIM fetches its fragments explicitly.
+                                          //  NOT an empty statement: hipcc's hazard recognizer counts every asm statement as one wait state)
             // alpha = float32(t/T) resp. float32(1 - t/T) as torch forms them (python double, then
             // cast); t * (1/T) in fp64 differs from t/T by < 1 ulp(fp64), invisible after the cast.
             float alpha;
@@ -795,6 +815,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
             if (PREC == BSDFD_PREC_F32) {
                 for (int layer = 0; layer < n_hidden; ++layer) {
                     const bool last = (layer == n_hidden - 1);
+                    if (NH == 0) loop_head_pad<NM, JAC>(z, zt0, zt1);
                     float h[NM][4], t0[NM][4], t1[NM][4];
 #pragma unroll
                     for (int m = 0; m < NM; ++m)
@@ -1189,6 +1210,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
 #pragma unroll
                 for (int layer = 0; layer < n_hidden; ++layer) {
                     const bool last = (layer == n_hidden - 1);
+                    if (NH == 0) loop_head_pad<NM, JAC>(z, zt0, zt1);
                     // first hidden layer of a disk net: folded tangents (FOLD_L1 above) — split g, not t_0 and t_1
                     const bool fold = FOLD_L1 && layer == 0 && !last;
                     const bool pen = foldout && layer == n_hidden - 2;   // the tangents stop here (see FOLDOUT)

@@ -404,15 +404,21 @@ _ZN12_GLOBAL__N_111flow_kernelILi1ELi2ELi2ELb1ELi4ELb0EEEvNS_7KParamsE:
 
 def test_asmcheck_flags_an_mfma_result_read_before_its_wait_states():
     """The pattern hipcc 7.2 emitted in round 4 (an MFMA right in front of a taken branch, its result read two instructions into
-    the target block): flagged; with the padding in place, with an intervening MFMA, or when the reader is another MFMA: clean."""
+    the target block): flagged; with the padding in place or when the reader is another MFMA: clean."""
     from bsdf_diffusion_sampling_amd import _asmcheck as A
     key = "flow_kernelILi1ELi2ELi2ELb1ELi4ELb0E"
     n, bad = A.check_mfma_hazards_lines(_ASM_HAZARD.splitlines(), key)
     assert n == 1 and len(bad) == 1 and "reads the destination" in bad[0] and "after 2 wait states (needs 10)" in bad[0]
     ok = _ASM_HAZARD.replace("\ts_waitcnt vmcnt(0)", "\ts_waitcnt vmcnt(0)\n\ts_nop 7")
     assert A.check_mfma_hazards_lines(ok.splitlines(), key) == (1, [])
-    ok2 = _ASM_HAZARD.replace("\ts_waitcnt vmcnt(0)", "\ts_waitcnt vmcnt(0)\n\tv_mfma_f32_16x16x4_f32 v[40:43], v29, v0, v[40:43]")   # + 8 passes of matrix-pipe time
-    assert A.check_mfma_hazards_lines(ok2.splitlines(), key)[1] == []
+    # an intervening MFMA counts ONE wait state (as in the compiler's own rule), not its passes: still flagged
+    mm = _ASM_HAZARD.replace("\ts_waitcnt vmcnt(0)", "\ts_waitcnt vmcnt(0)\n\tv_mfma_f32_16x16x4_f32 v[40:43], v29, v0, v[40:43]")
+    assert "after 3 wait states (needs 10)" in A.check_mfma_hazards_lines(mm.splitlines(), key)[1][0]
+    # the 4-pass fp16 shape needs 8 states before a VALU read (LLVM gfx950: passes + 4), one short is flagged
+    x16 = _ASM_HAZARD.replace("v_mfma_f32_16x16x4_f32 v[10:13], v29, v0, v[30:33]", "v_mfma_f32_16x16x32_f16 v[10:13], v[26:29], v[0:3], v[30:33]")
+    short = x16.replace("\ts_waitcnt vmcnt(0)", "\ts_waitcnt vmcnt(0)\n\ts_nop 4")
+    assert "after 7 wait states (needs 8)" in A.check_mfma_hazards_lines(short.splitlines(), key)[1][0]
+    assert A.check_mfma_hazards_lines(x16.replace("\ts_waitcnt vmcnt(0)", "\ts_waitcnt vmcnt(0)\n\ts_nop 5").splitlines(), key)[1] == []
     ok3 = _ASM_HAZARD.replace("\tv_mul_f32_e32 v0, 0x3fb8aa3b, v13", "\tv_mfma_f32_16x16x4_f32 v[10:13], v29, v0, v[10:13]")
     assert A.check_mfma_hazards_lines(ok3.splitlines(), key)[1] == []
     waw = _ASM_HAZARD.replace("\tv_mul_f32_e32 v0, 0x3fb8aa3b, v13", "\tv_mov_b32_e32 v12, 0")
