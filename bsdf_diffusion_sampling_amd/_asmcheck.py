@@ -240,3 +240,66 @@ def check_file_mfma(path: str, fragment: str = "flow_kernel") -> Dict[str, Tuple
     """Every kernel of the assembly file whose name contains ``fragment`` -> (MFMAs, missing-wait-state violations)."""
     lines = open(path).read().splitlines()
     return {k: check_mfma_hazards_lines(lines, k) for k in kernel_names(lines, fragment)}
+
+
+# VALU write of a VGPR -> v_permlane{16,32}_swap touching it: 2 wait states (LLVM's gfx950 rule, cdna_hip_programming.md §4:
+# "VALU write of either swap operand must be followed by 2 wait states").  The compiler pads these too; checked for the same
+# reason as the MFMA results above (the reductions of the Jacobian run through these swaps).
+SWAP_WAIT = 2
+
+
+def check_swap_hazards_lines(lines: List[str], key: str) -> Tuple[int, List[str]]:
+    """(number of v_permlane*_swap instructions, violations): every VALU instruction that writes a register a later
+    v_permlane16_swap / v_permlane32_swap reads or exchanges must be SWAP_WAIT wait states ahead of it on every path."""
+    body = kernel_body(lines, key)
+    ins, label_at = [], {}
+    for raw in body:
+        code = raw.split(";")[0].strip()
+        if not code or code.startswith("."):
+            m = re.match(r"^(\.LBB\d+_\d+):", code)
+            if m:
+                label_at[m.group(1)] = len(ins)
+            continue
+        if code.endswith(":"):
+            label_at[code[:-1]] = len(ins)
+            continue
+        toks = [t.strip(",") for t in code.split()]
+        ins.append((toks[0], toks[1:], code))
+    n_swap = sum(1 for o, _, _ in ins if o.startswith("v_permlane") and "swap" in o)
+    bad = []
+    for i, (op, toks, code) in enumerate(ins):
+        if not op.startswith("v_") or op.startswith("v_cmp") or op.startswith("v_readlane") or op.startswith("v_readfirstlane") \
+                or op.startswith("v_mfma") or op.startswith("v_smfmac") or not toks:
+            continue
+        dst = _regs(toks[0])
+        if op.startswith("v_permlane") and "swap" in op and len(toks) > 1:
+            dst = dst | _regs(toks[1])   # a swap writes both operands
+        if not dst:
+            continue
+        stack, seen = [(i + 1, 0)], {}
+        while stack:
+            j, w = stack.pop()
+            while j < len(ins) and w < SWAP_WAIT:
+                if seen.get(j, 1 << 30) <= w:
+                    break
+                seen[j] = w
+                o, t, c = ins[j]
+                if o.startswith("v_permlane") and "swap" in o and len(t) > 1 and dst & (_regs(t[0]) | _regs(t[1])):
+                    bad.append(f"`{c}` exchanges a register `{code}` wrote {w} wait states earlier (needs {SWAP_WAIT})")
+                    stack.clear()
+                    break
+                if o == "s_endpgm":
+                    break
+                m = re.search(r"(\.LBB\d+_\d+)", c) if o.startswith("s_cbranch") or o == "s_branch" else None
+                if m and m.group(1) in label_at:
+                    stack.append((label_at[m.group(1)], w + 1))
+                    if o == "s_branch":
+                        break
+                w += int(t[0], 0) + 1 if (o == "s_nop" and t) else 1
+                j += 1
+    return n_swap, bad
+
+
+def check_file_swap(path: str, fragment: str = "flow_kernel") -> Dict[str, Tuple[int, List[str]]]:
+    lines = open(path).read().splitlines()
+    return {k: check_swap_hazards_lines(lines, k) for k in kernel_names(lines, fragment)}

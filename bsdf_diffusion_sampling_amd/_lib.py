@@ -92,7 +92,13 @@ def _check_asm_mfma(asm_path: str):
     leaving the padding out behind a taken branch (csrc/bsdfd.hip, the base-net MFMAs), silently computing with a stale
     accumulator — there is no fallback for this class, the build refuses to ship."""
     from . import _asmcheck
-    return {k: bad for k, (n, bad) in _asmcheck.check_file_mfma(asm_path).items() if bad}
+    out = {k: bad for k, (n, bad) in _asmcheck.check_file_mfma(asm_path).items() if bad}
+    # ... and the second class of software-managed hazards these kernels rely on: a VALU write followed by a v_permlane*_swap of
+    # the same register (2 wait states; the Jacobian's lane reductions run through these swaps)
+    for k, (n, bad) in _asmcheck.check_file_swap(asm_path).items():
+        if bad:
+            out.setdefault(k, []).extend(bad)
+    return out
 
 
 def _compile_flow_tu(td: str, extra, verbose: bool):
@@ -164,10 +170,11 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
             hz = _check_asm_mfma(asm)
             if hz:
                 first = next(iter(hz.items()))
-                raise RuntimeError("bsdfd build: this toolchain's compilation of csrc/bsdfd.hip reads or overwrites MFMA results "
+                raise RuntimeError("bsdfd build: this toolchain's compilation of csrc/bsdfd.hip reads or overwrites MFMA results (or "
+                                   "swaps lanes of a freshly written register) "
                                    f"before the wait states the ISA requires, in {len(hz)} kernel(s) — e.g. {first[0]}: {first[1][0]}.  "
-                                   "The library would compute with stale accumulators; refusing to ship it "
-                                   "(bsdf_diffusion_sampling_amd/_asmcheck.py: check_mfma_hazards_lines).")
+                                   "The library would compute with stale registers; refusing to ship it "
+                                   "(bsdf_diffusion_sampling_amd/_asmcheck.py: check_mfma_hazards_lines, check_swap_hazards_lines).")
         finally:
             for cmd, pr in procs:
                 if pr.wait() != 0:

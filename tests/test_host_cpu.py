@@ -427,6 +427,23 @@ def test_asmcheck_flags_an_mfma_result_read_before_its_wait_states():
     assert A.check_mfma_hazards_lines(ld.splitlines(), key)[1] == []
 
 
+def test_asmcheck_flags_a_lane_swap_of_a_freshly_written_register():
+    from bsdf_diffusion_sampling_amd import _asmcheck as A
+    key = "flow_kernelILi1ELi2ELi2ELb1ELi4ELb0E"
+    head = "_ZN12_GLOBAL__N_111flow_kernelILi1ELi2ELi2ELb1ELi4ELb0EEEvNS_7KParamsE:\n"
+    tail = "\ts_endpgm\n"
+    bad = head + "\tv_mul_f32_e32 v16, v16, v17\n\tv_mov_b32_e32 v3, v4\n\tv_permlane16_swap_b32_e32 v16, v17\n" + tail
+    n, msgs = A.check_swap_hazards_lines(bad.splitlines(), key)
+    assert n == 1 and len(msgs) == 1 and "1 wait states earlier (needs 2)" in msgs[0]
+    ok = bad.replace("\tv_mov_b32_e32 v3, v4\n", "\tv_mov_b32_e32 v3, v4\n\ts_nop 0\n")
+    assert A.check_swap_hazards_lines(ok.splitlines(), key) == (1, [])
+    # through a taken branch (one state) as well; a swap's own results feeding the next swap count too
+    br = head + "\tv_mul_f32_e32 v16, v16, v17\n\ts_cbranch_vccnz .LBB0_2\n\ts_nop 7\n.LBB0_2:\n\tv_permlane32_swap_b32_e32 v16, v17\n" + tail
+    assert len(A.check_swap_hazards_lines(br.splitlines(), key)[1]) == 1
+    chain = head + "\tv_permlane32_swap_b32_e32 v16, v17\n\tv_permlane16_swap_b32_e32 v17, v18\n" + tail
+    assert len(A.check_swap_hazards_lines(chain.splitlines(), key)[1]) == 1
+
+
 def test_build_refuses_to_ship_when_mfma_results_are_consumed_too_early(tmp_path, monkeypatch):
     import shutil
     if not shutil.which("hipcc"):

@@ -125,6 +125,11 @@ def main():
                 for x in b[:2]:
                     print("  ", k, x)
             rc |= bool(n_bad)
+            from bsdf_diffusion_sampling_amd._asmcheck import check_file_swap
+            sw = check_file_swap(asm)
+            n_bad = sum(1 for _, b in sw.values() if b)
+            print(f"lane swaps of a register written fewer than 2 wait states earlier: {n_bad} of {len(sw)} kernels, {sum(n for n, _ in sw.values())} swaps checked")
+            rc |= bool(n_bad)
         return rc
     print(json.dumps(model(sys.argv[1], sys.argv[2]), indent=1))
 
