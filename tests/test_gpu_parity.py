@@ -59,7 +59,7 @@ def _resolved(ref, acc):
 
 
 def _record(name, **kv):
-    """Achieved error figures, kept next to the run (gpurun_out/ is scratch; the committed copy is profiles/r03_plugin_parity.json)."""
+    """Achieved error figures, kept next to the run (gpurun_out/ is scratch; the committed copies are profiles/r0N_plugin_parity.json)."""
     import json
     import os
     from conftest import ROOT
