@@ -285,17 +285,39 @@ __device__ __forceinline__ float fast_acos(float x) {
 // the pole both give sqrt(2 eps)), 1.5e-7 rad from the fp64 value on the same fixtures.  `ref_pole`: where the reference's fp32
 // quotient is not inside (-1, 1) its theta is 0, pi or NaN and its sin(theta) > 5e-5 guard zeroes the density: pdf() keeps that
 // decision (rendering/brdf_measured_spherical.py:134).
-__device__ __forceinline__ void cart_to_spher(float x, float y, float z, float& theta, float& phi, bool& ref_pole) {
+//
+// Both angles are an atan2f of different arguments, and every lane of a query would evaluate them redundantly (~50 VALU
+// instructions each; a pdf() launch needs four: theta and phi of wi and of wo).  So the four lanes of a query take ONE angle
+// each - lane (g, q) evaluates job g & (NJ - 1) - and the results are handed round with ds_bpermute (the LDS crossbar, not
+// the VALU): bit-identical to the redundant evaluation, 150 VALU instructions per tile less in a spherical pdf() launch, 50 in a
+// sample() launch (tools/pro_count.sh counted 557 resp. 740 outside the Euler loop before).
+struct SphArgs {        // theta = atan2(s, z), phi = atan2(y, x)
+    float s, z, y, x;
+    bool ref_pole;
+};
+__device__ __forceinline__ SphArgs spher_args(float x, float y, float z) {
     const float eps = 1e-8f;
     const float s2 = x * x + y * y;
     const float r = sqrtf(s2 + z * z);
-#ifdef BSDFD_TOOLS_ACOS_AS_WRITTEN   // (tools/ab_build.sh: the reference's form, for within-run A/B of time and accuracy)
-    theta = acosf(z / (r + eps));
-#else
-    theta = atan2f(sqrtf(s2 + (2.0f * r * eps + eps * eps)), z);
-#endif
-    phi = atan2f(y, x);
-    ref_pole = !(fabsf(z / (r + eps)) < 1.0f);
+    SphArgs a;
+    a.s = sqrtf(s2 + (2.0f * r * eps + eps * eps));
+    a.z = z; a.y = y; a.x = x;
+    a.ref_pole = !(fabsf(z / (r + eps)) < 1.0f);
+    return a;
+}
+template <int NJ>   // NJ = 2 or 4 jobs (Y[k], X[k]); out[k] = atan2f(Y[k], X[k]) in every lane of the query
+__device__ __forceinline__ void atan2_by_lane(const float (&Y)[NJ], const float (&X)[NJ], int g, int q, float (&out)[NJ]) {
+    static_assert(NJ == 2 || NJ == 4, "jobs are dealt to the 4 lanes of a query");
+    const int j = g & (NJ - 1);
+    float yy = Y[0], xx = X[0];
+#pragma unroll
+    for (int k = 1; k < NJ; ++k) {
+        yy = j == k ? Y[k] : yy;
+        xx = j == k ? X[k] : xx;
+    }
+    const float a = atan2f(yy, xx);
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) out[k] = __shfl(a, 16 * k + q, 64);   // row k of the wave holds job k
 }
 
 // log I0(kappa): the two polynomials of torch.distributions.von_mises._log_modified_bessel_fn
@@ -526,15 +548,25 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
         // per-query context: a launch that is handed the context an earlier sample / pdf launch wrote for the SAME wi array
         // skips everything below that depends on wi alone (cart_to_spher(wi), encoding, conditioning term, base net)
         const bool have_ctx = !FUSED && p.ctx_in != nullptr;
-        auto load_dir = [&](const float* dir) {  // plugin io: the direction whose pdf is asked -> start point of the reverse flow
+        // plugin io: the direction whose pdf is asked -> start point of the reverse flow.  Disk: its xy; spherical: the arguments of
+        // its two angles (evaluated below, one atan2f per lane, together with those of wi where both are needed)
+        SphArgs ao = {};
+        auto load_dir = [&](const float* dir) {
             const float ox = dir[qi * 3 + 0], oy = dir[qi * 3 + 1], oz = dir[qi * 3 + 2];
             wo_z = oz;
             wo_sin = sqrtf(ox * ox + oy * oy);  // Mitsuba Frame3f::sin_theta
             if (DOMAIN == BSDFD_DOMAIN_DISK) {
                 xs0 = ox; xs1 = oy;
             } else {
-                cart_to_spher(ox, oy, oz, xs0, xs1, wo_pole);
+                ao = spher_args(ox, oy, oz);
+                wo_pole = ao.ref_pole;
             }
+        };
+        auto angles_of = [&](const SphArgs& a, float& theta, float& phi) {   // two jobs: lanes g = 0, 2 theta, g = 1, 3 phi
+            const float Y[2] = {a.s, a.y}, X[2] = {a.z, a.x};
+            float r[2];
+            atan2_by_lane<2>(Y, X, g, q, r);
+            theta = r[0]; phi = r[1];
         };
         if (p.io == IO_OPERATOR) {
             const float2 c2 = reinterpret_cast<const float2*>(p.in_a)[qi];
@@ -548,11 +580,22 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
             wi_z = wz;
             if (DOMAIN == BSDFD_DOMAIN_DISK) {
                 y0 = wx; y1 = wy;  // rendering/brdf_measured_disk.py:66-67
-            } else if (!have_ctx) {  // rendering/brdf_measured_spherical.py:35-39
-                bool unused;
-                cart_to_spher(wx, wy, wz, y0, y1, unused);
             }
-            if (!FUSED && p.op == OP_PDF) load_dir(p.in_b);  // (the fused kernel loads wl at its phase switch: 4 registers less across phase 1)
+            const bool need_o = !FUSED && p.op == OP_PDF;
+            if (need_o) load_dir(p.in_b);  // (the fused kernel loads wl at its phase switch: 4 registers less across phase 1)
+            if (DOMAIN == BSDFD_DOMAIN_SPHERICAL) {  // cart_to_spher, rendering/brdf_measured_spherical.py:35-39 (wave-uniform branches)
+                if (!have_ctx && need_o) {           // pdf(): four angles, one per lane of the query
+                    const SphArgs ai = spher_args(wx, wy, wz);
+                    const float Y[4] = {ai.s, ai.y, ao.s, ao.y}, X[4] = {ai.z, ai.x, ao.z, ao.x};
+                    float r[4];
+                    atan2_by_lane<4>(Y, X, g, q, r);
+                    y0 = r[0]; y1 = r[1]; xs0 = r[2]; xs1 = r[3];
+                } else if (!have_ctx) {
+                    angles_of(spher_args(wx, wy, wz), y0, y1);
+                } else if (need_o) {
+                    angles_of(ao, xs0, xs1);
+                }
+            }
             if ((FUSED || p.op != OP_PDF) && p.in_b != nullptr) {  // injected base sample
                 const float2 b2 = reinterpret_cast<const float2*>(p.in_b)[qi];
                 if (FUSED) { xi0 = b2.x; xi1 = b2.y; } else { xs0 = b2.x; xs1 = b2.y; }
@@ -674,7 +717,10 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
         const float cstep = FUSED ? (ph ? -invT : invT) : cstep1;
         float* const out_pdf = (FUSED && ph) ? p.out_pdf2 : p.out_pdf;
         // ---------------- initial state ------------------------------------------------------------
-        if (FUSED && ph) load_dir(p.in_c);
+        if (FUSED && ph) {
+            load_dir(p.in_c);
+            if (DOMAIN == BSDFD_DOMAIN_SPHERICAL) angles_of(ao, xs0, xs1);
+        }
         float x0 = (FUSED && !ph) ? xi0 : xs0, x1 = (FUSED && !ph) ? xi1 : xs1;
         if (op == OP_SAMPLE && p.in_b == nullptr) {  // draw x0 ~ D_base(. | omega_i) in-kernel
             const unsigned long long ctr = p.offset + (unsigned long long)(p.rng_index ? p.rng_index[qi] : qi);
