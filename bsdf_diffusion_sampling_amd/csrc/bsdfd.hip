@@ -414,9 +414,13 @@ __device__ __forceinline__ float von_mises_sample(float mu, float kappa, unsigne
 // 156-VGPR schedule it produces when asked for 3 (profiles/r03_ab/ab13).  tools/isa_mix.py --check-async (a CPU test) fails
 // if a toolchain ever takes that kernel past 168 VGPRs, i.e. down to 2 waves/SIMD (which measured 4 % slower on the
 // spherical kernel).
+// The 64-wide kernels WITHOUT the Jacobian (the reflow teacher sampler, f16 / f32) need ~127 VGPRs in their loop = 4 waves/SIMD;
+// the per-tile prologue they share with every other instantiation once grew past 128 and took the teacher from 4 to 3 waves
+// (-4 %, round 4): they are pinned to 4.
 // (written without commas: __launch_bounds__ is a variadic macro)
 #define BSDFD_MIN_WAVES \
-    (NM != 2 ? 2 : ((DOMAIN == BSDFD_DOMAIN_DISK && PREC == BSDFD_PREC_SPLIT3 && JAC && NH == 3 && !FUSED) ? 2 : 3))
+    (NM != 2 ? ((!JAC && PREC != BSDFD_PREC_SPLIT3) ? 4 : 2) \
+             : ((DOMAIN == BSDFD_DOMAIN_DISK && PREC == BSDFD_PREC_SPLIT3 && JAC && NH == 3 && !FUSED) ? 2 : 3))
 template <int DOMAIN, int NM, int PREC, bool JAC, int NH, bool FUSED>
 __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_kernel(const KParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

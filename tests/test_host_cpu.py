@@ -348,6 +348,8 @@ def test_asynchronous_lds_reads_are_not_touched_before_their_wait():
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(", 0 violations") == 8 and "25 asynchronous" in r.stdout and "21 asynchronous" in r.stdout
     assert "MFMA results consumed before their wait states: 0 of 54 kernels" in r.stdout
+    assert "lane swaps of a register written fewer than 2 wait states earlier: 0 of 54 kernels" in r.stdout
+    assert r.stdout.count("occupancy ") == 4 and "LOST" not in r.stdout, r.stdout   # 3 / 3 / 4 / 2 waves/SIMD of the tracked kernels
 
 
 _ASM_OK = """

@@ -125,6 +125,18 @@ def main():
                 for x in b[:2]:
                     print("  ", k, x)
             rc |= bool(n_bad)
+            # occupancy of the kernels behind the tracked workloads (waves/SIMD the VGPR allocation allows): a prologue edit shared
+            # by all instantiations once took the teacher sampler from 4 to 3 waves unnoticed (round 4, -4 %)
+            from bsdf_diffusion_sampling_amd._asmcheck import kernel_meta
+            lines = open(asm).read().splitlines()
+            for name, key, want in (("disk 32x3 split3 (disk_1Mi_T8 / T4)", "flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E", 3),
+                                    ("spherical 32x4 split3 (spherical_16Mi_T8)", "flow_kernelILi1ELi2ELi2ELb1ELi4ELb0E", 3),
+                                    ("teacher 64x6 f16, no Jacobian", "flow_kernelILi1ELi4ELi3ELb0ELi6ELb0E", 4),
+                                    ("64x6 split3 with Jacobian (complex64_1Mi_T8)", "flow_kernelILi1ELi4ELi2ELb1ELi6ELb0E", 2)):
+                v = kernel_meta(lines, key).get("vgpr_count", 0)
+                waves = 8 if v <= 64 else 512 // ((v + 7) // 8 * 8)
+                print(f"occupancy {name}: {v} VGPRs = {waves} waves/SIMD (wanted {want}){'' if waves >= want else '  <-- LOST'}")
+                rc |= waves < want
             from bsdf_diffusion_sampling_amd._asmcheck import check_file_swap
             sw = check_file_swap(asm)
             n_bad = sum(1 for _, b in sw.values() if b)
