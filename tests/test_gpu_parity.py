@@ -186,6 +186,32 @@ def test_ragged_sizes(n):
         assert torch.all(big[n:] == -7.0)
 
 
+@pytest.mark.parametrize("n", [1, 7, 17, 1000])
+def test_spherical_plugin_ragged_tile_equals_the_padded_launch(n):
+    """The spherical plugins deal the atan2f evaluations of cart_to_spher to the four lanes of a query and hand the results
+    round by lane shuffles (csrc/bsdfd.hip, atan2_by_lane): a partial last tile must give, row for row, what the same rows
+    give inside a full launch - sample(), pdf() without and with the per-query context, and the fused call."""
+    g, fw = load_case("chm_orange_rgb_spherical")
+    s = _sampler(fw, "split3")
+    rng = np.random.default_rng(n)
+    full = 1024 + 16
+    wi3 = _dir(rng.uniform(0.01, 1.5, full), rng.uniform(-np.pi, np.pi, full))
+    wl3 = _dir(rng.uniform(0.01, 1.5, full), rng.uniform(-np.pi, np.pi, full))
+    x0 = np.tile(g["x0"], (2, 1))[:full]
+    wo_f, p_f = s.plugin_sample(_t(wi3), _t(x0), T=8)
+    q_f = s.plugin_pdf(_t(wi3), _t(wl3), T=8)
+    wo_n, p_n = s.plugin_sample(_t(wi3[:n]), _t(x0[:n]), T=8)
+    ctx = s.new_context(n)
+    q_n = s.plugin_pdf(_t(wi3[:n]), _t(wl3[:n]), T=8, ctx_out=ctx)
+    q_c = s.plugin_pdf(_t(wi3[:n]), _t(wl3[:n]), T=8, ctx_in=ctx)
+    assert torch.equal(wo_n, wo_f[:n]) and torch.equal(p_n, p_f[:n])
+    assert torch.equal(q_n, q_f[:n]) and torch.equal(q_c, q_f[:n])
+    wo_u, p_u, q_u = s.plugin_sample_pdf(_t(wi3[:n]), _t(wl3[:n]), _t(x0[:n]), T=8)
+    wo_g, p_g, q_g = s.plugin_sample_pdf(_t(wi3), _t(wl3), _t(x0), T=8)
+    assert torch.equal(wo_u, wo_g[:n]) and torch.equal(p_u, p_g[:n]) and torch.equal(q_u, q_g[:n])
+    assert torch.isfinite(q_n).all() and (q_n > 0).any()
+
+
 def _wi3_disk(wi2):
     return np.concatenate([wi2, np.sqrt(np.maximum(1 - (wi2 ** 2).sum(1), 0))[:, None]], 1).astype(np.float32)
 
