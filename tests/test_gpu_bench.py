@@ -69,6 +69,14 @@ def test_bench_line_single_gpu_with_secondary_and_cpu_baseline():
     assert d["encoding_pass"]["bound"] == "hbm" and d["encoding_pass"]["frac"] > 0.3
 
 
+def test_bench_with_the_per_query_context_opted_in():
+    """--context on: sample() hands the context to pdf(); the looked-up HBM traffic (PMC passes of the DEFAULT command) is withheld."""
+    d = _run(["--gpus", "1", "--context", "on"] + FAST)
+    _check_contract(d, 1, "disk_1Mi_T8")
+    assert d["config"]["per_query_context"] is True and d["roofline"]["traffic"] is None
+    assert "context" in d["roofline"]["traffic_note"]
+
+
 @pytest.mark.parametrize("workload", ["disk_1Mi_T8", "mixed_16Mi"])
 def test_bench_self_launches_two_ranks(workload):
     one = _run(["--gpus", "1", "--workload", workload] + FAST)
