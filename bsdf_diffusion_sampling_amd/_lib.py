@@ -13,10 +13,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("BSDFD_LIB_PATH") or os.path.join(_HERE, "libbsdfd.so")  # override: A/B builds
 SRC_PATH = os.path.join(_HERE, "csrc", "bsdfd.hip")
-SRC_PATHS = [SRC_PATH, os.path.join(_HERE, "csrc", "wavefront.hip"), os.path.join(_HERE, "csrc", "encoding.hip"),
+SRC32_PATH = os.path.join(_HERE, "csrc", "flow32.hip")   # the 32-query-tile flow kernels
+SRC_PATHS = [SRC_PATH, SRC32_PATH, os.path.join(_HERE, "csrc", "wavefront.hip"), os.path.join(_HERE, "csrc", "encoding.hip"),
              os.path.join(_HERE, "csrc", "measured.hip"), os.path.join(_HERE, "csrc", "bucket.hip"),
              os.path.join(_HERE, "csrc", "clock.hip")]  # translation units of libbsdfd.so
-DEP_PATHS = SRC_PATHS + [os.path.join(_HERE, "csrc", "common.h")]
+FLOW_TUS = (SRC_PATH, SRC32_PATH)   # ... whose device assembly the build verifies (_asmcheck)
+DEP_PATHS = SRC_PATHS + [os.path.join(_HERE, "csrc", f) for f in ("common.h", "flow_dev.h", "flow32.h")]
 INCLUDE_DIR = os.path.join(ROOT, "include")
 
 PREC_DEFAULT, PREC_F32, PREC_SPLIT3, PREC_F16 = 0, 1, 2, 3
@@ -68,7 +70,7 @@ def opts(ctx_out=None, ctx_in=None, rng_index=None, byte_offset_rng: int = 0):
 
 class Desc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("domain", "width", "n_hidden", "pe_bands", "base_hidden",
-                                         "base_pe_bands", "precision", "reserved")] + \
+                                         "base_pe_bands", "precision", "tile")] + \
                [(n, C.POINTER(C.c_float)) for n in ("w_in", "w_hidden", "w_out", "base_w1", "base_b1",
                                                     "base_w2", "base_b2")]
 
@@ -101,19 +103,32 @@ def _check_asm_mfma(asm_path: str):
     return out
 
 
-def _compile_flow_tu(td: str, extra, verbose: bool):
-    """Compile csrc/bsdfd.hip to td/bsdfd.o keeping the device assembly of THIS compilation (-save-temps=obj)."""
+def _flow_tu_cmd(td: str, src: str, extra):
+    stem = os.path.basename(src)[:-4]
+    return ["hipcc", *HIPCC_FLAGS, *extra, "-save-temps=obj", "-I", INCLUDE_DIR, "-c", src, "-o", os.path.join(td, stem + ".o")]
+
+
+def _flow_tu_asm(td: str, src: str) -> str:
     import glob
-    for f in glob.glob(os.path.join(td, "bsdfd*")):
-        os.remove(f)
-    cmd = ["hipcc", *HIPCC_FLAGS, *extra, "-save-temps=obj", "-I", INCLUDE_DIR, "-c", SRC_PATH, "-o", os.path.join(td, "bsdfd.o")]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=td)
-    asm = [f for f in glob.glob(os.path.join(td, "bsdfd*.s")) if "gfx950" in os.path.basename(f)]
+    stem = os.path.basename(src)[:-4]
+    asm = [f for f in glob.glob(os.path.join(td, stem + "*.s")) if "gfx950" in os.path.basename(f)]
     if len(asm) != 1:
         raise RuntimeError(f"expected one gfx950 assembly file from -save-temps, found {asm}")
     return asm[0]
+
+
+def _compile_flow_tu(td: str, extra, verbose: bool, src: str = None):
+    """Compile a flow-kernel translation unit (default csrc/bsdfd.hip) to td/<stem>.o keeping the device assembly of THIS
+    compilation (-save-temps=obj); returns the path of that assembly."""
+    import glob
+    src = src or SRC_PATH
+    for f in glob.glob(os.path.join(td, os.path.basename(src)[:-4] + "*")):
+        os.remove(f)
+    cmd = _flow_tu_cmd(td, src, extra)
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=td)
+    return _flow_tu_asm(td, src)
 
 
 def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> str:
@@ -143,15 +158,26 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
     except OSError:
         pass
     with tempfile.TemporaryDirectory(prefix="bsdfd_build_") as td:
-        side = []
-        procs = []
-        for src in SRC_PATHS[1:]:   # the side translation units in parallel with the flow kernels
+        side, procs = [], []
+        for src in SRC_PATHS[1:]:   # the other translation units in parallel with csrc/bsdfd.hip (the long one)
             obj = os.path.join(td, os.path.basename(src)[:-4] + ".o")
             side.append(obj)
-            cmd = ["hipcc", *HIPCC_FLAGS, "-I", INCLUDE_DIR, "-c", src, "-o", obj]
+            cmd = _flow_tu_cmd(td, src, []) if src in FLOW_TUS else ["hipcc", *HIPCC_FLAGS, "-I", INCLUDE_DIR, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            procs.append((cmd, subprocess.Popen(cmd)))
+            procs.append((cmd, subprocess.Popen(cmd, cwd=td)))
+
+        def reap(kill: bool):
+            """Wait for (or kill) every child; the first failed command, or None.  Never raises: it also runs while another
+            exception is in flight, which it must not replace."""
+            failed = None
+            for cmd, pr in procs:
+                if kill and pr.poll() is None:
+                    pr.kill()
+                if pr.wait() != 0 and failed is None and not kill:
+                    failed = (pr.returncode, cmd)
+            return failed
+
         try:
             asm = _compile_flow_tu(td, [], verbose)
             bad = _check_asm(asm)
@@ -167,18 +193,22 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
                 still = _check_asm(asm)
                 if still:
                     raise RuntimeError(f"the fallback build still fails the assembly check: {still}")
-            hz = _check_asm_mfma(asm)
+        except BaseException:
+            reap(kill=True)
+            raise
+        failed = reap(kill=False)
+        if failed:
+            raise subprocess.CalledProcessError(*failed)
+        asms = [asm] + [_flow_tu_asm(td, src) for src in FLOW_TUS[1:]]
+        for a in asms:
+            hz = _check_asm_mfma(a)
             if hz:
                 first = next(iter(hz.items()))
-                raise RuntimeError("bsdfd build: this toolchain's compilation of csrc/bsdfd.hip reads or overwrites MFMA results (or "
+                raise RuntimeError(f"bsdfd build: this toolchain's compilation of {os.path.basename(a)} reads or overwrites MFMA results (or "
                                    "swaps lanes of a freshly written register) "
                                    f"before the wait states the ISA requires, in {len(hz)} kernel(s) — e.g. {first[0]}: {first[1][0]}.  "
                                    "The library would compute with stale registers; refusing to ship it "
                                    "(bsdf_diffusion_sampling_amd/_asmcheck.py: check_mfma_hazards_lines, check_swap_hazards_lines).")
-        finally:
-            for cmd, pr in procs:
-                if pr.wait() != 0:
-                    raise subprocess.CalledProcessError(pr.returncode, cmd)
         cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(td, "bsdfd.o"), *side, "-o", tmp]
         if verbose:
             print(" ".join(cmd), flush=True)

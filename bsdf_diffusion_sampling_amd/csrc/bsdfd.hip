@@ -45,358 +45,10 @@
 #include "common.h"
 
 
+#include "flow_dev.h"
+#include "flow32.h"
+
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-constexpr int PE_BANDS = 5;       // rendering/brdf_measured_disk.py:43 (POSITIONAL_ENCODING_BASIS_NUM=5)
-constexpr int BASE_PE_BANDS = 3;  // :49
-constexpr int BASE_HIDDEN = 16;
-constexpr int PE_SLABS = PE_BANDS + 1;  // K=4 slabs: one per band (sin/cos x 2 dims) + the raw (y0,y1) slab
-// Split-fp16 operands: x = hi + lo with hi = x truncated to fp16's 11 significant bits (one v_and)
-// and lo = fp16(x - hi).  lo may be an fp16 subnormal; the gfx950 MFMA honours fp16 subnormal
-// inputs (measured: tools/ubench/denorm.hip), so no rescaling is needed and all three products
-// hi*hi + hi*lo + lo*hi accumulate into ONE fp32 accumulator.
-
-enum { OP_SAMPLE = 0, OP_PDF = 1, OP_SAMPLES_ONLY = 2, OP_SAMPLE_PDF = 3 };  // 3: plugin io only, sample(wi) then pdf(wi, wl)
-// Precision of the TANGENT contractions: 3 = hi+lo operands and the W_lo product, like the activations.  Cheaper settings
-// were measured and rejected (2: operands rounded to fp16, -29 % time, p99 pdf error 4e-4 .. 7e-3; 1: single product,
-// 7e-4 .. 8e-3 — the 2x2 determinant of a sharp lobe cancels heavily); the ablation builds live in git history
-// (commit 5a33ef0), not in the product source.
-constexpr int kTangentPrec = 3;
-constexpr int CLK_SLOTS = 256;  // counter pairs of the in-kernel clock measurement, 8 u64 (one 64-B line) apart
-constexpr int MAX_SEG = 64;  // materials per segmented launch (the descriptors travel in the kernel arguments)
-enum { IO_OPERATOR = 0, IO_PLUGIN = 1, IO_PLUGIN_FULLSPHERE = 2 };
-
-struct ImgLayout {  // byte offsets into the weight image (identical in global memory and LDS)
-    int win, wc, wh, wh_lo, wo, wf, wf_lo, wg, wg_lo, bw1, bb1, bw2, bb2, wcs, wcs_lo, wt0, total;
-};
-
-struct KParams {
-    const char* img;
-    ImgLayout L;
-    const float* in_a;   // operator: omega_i [N,2]   plugin: wi [N,3]
-    const float* in_b;   // sample: x0 [N,2] or null  pdf: omega_o [N,2] / wo [N,3]
-    float* out_x;        // sample: x [N,2] / wo [N,3]
-    float* out_pdf;      // [N]
-    long long N;
-    int T;
-    int n_hidden;
-    int op;
-    int io;
-    unsigned long long seed, offset;
-    // multi-material ("segmented") launch: the query arrays hold nseg contiguous buckets, one per
-    // material; workgroups [blk_begin, blk_end) of the grid serve bucket [q_begin, q_end) with that
-    // material's weight image.  nseg == 0: ordinary single-material launch over [0, N).
-    const float* in_c;   // OP_SAMPLE_PDF: wl [N,3], the direction whose pdf is asked
-    float* out_pdf2;     // OP_SAMPLE_PDF: pdf(wi, wl) [N]
-    // per-query context (everything derived from wi alone: conditioning term of layer 1 + base-net outputs), see
-    // bsdfd_context_bytes: written by whichever sample / pdf launch sees the wi array first (ctx_out), read instead of
-    // recomputed by the later ones (ctx_in)
-    float* ctx_out;
-    const float* ctx_in;
-    // sample: Philox counter of row i = offset + rng_index[i] (NULL: offset + i).  A bucketed wavefront passes the rows'
-    // ORIGINAL lane indices, so the draws do not depend on the bucketing, the sharding or the GPU count
-    const long long* rng_index;
-    // profiling only (else NULL): every wave adds its lifetime in shader cycles (s_memtime) and in ticks of the constant-rate
-    // wall clock (s_memrealtime) to one of CLK_SLOTS counter pairs (one 64-B line each: 16 Ki same-address atomics per launch
-    // cost a 0.25 ms launch 6 %); the ratio of the sums is the shader clock the kernel ran at (bsdfd_profile_clock_mhz).
-    // Both counters are read by the same wave, so per-CU counter offsets cancel.
-    unsigned long long* clk;
-    int seg_base;    // segmented launches: buckets served by EARLIER launches of the same call (context slot numbering)
-    int chunk_log2;  // a wave takes 2^chunk_log2 consecutive-ish tiles per chunk (see the tile map in the kernel)
-    int nseg;
-    struct Seg {
-        const char* img;
-        long long q_begin, q_end;
-        int blk_begin, blk_end;
-        int chunk_log2, pad;
-    } seg[MAX_SEG];
-};
-
-// ---------------------------------------------------------------------------------------------
-// device helpers
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-}
-
-// SiLU and its derivative from one sigmoid.  Every layer's weights are packed so that the MFMA
-// delivers zs = -log2(e) * z ("scaled pre-activation"): then sigma(z) = 1 / (1 + 2^zs) needs no
-// multiply in front of v_exp_f32, the layer's outputs are hs = zs * s = -log2(e) * silu(z) and
-// ts = zts * g = -log2(e) * t, and the NEXT layer's unscaled weights applied to (hs, ts) again
-// deliver scaled pre-activations.  The first layer's weights carry the factor -log2(e), the
-// output layer's carry -ln 2 (host packing, build_image).  silu'(z) = s + silu(z) (1 - s)
-// = fma(hs, -ln2 (1 - s), s).
-// v_exp_f32 / v_rcp_f32 are 1-ulp hardware transcendentals (quarter rate: the two of them are
-// ~15 of the ~55 VALU cycles a hidden unit costs per step).
-constexpr float kLog2e = 1.44269504088896340736f;
-constexpr float kLn2 = 0.69314718055994530942f;
-__device__ __forceinline__ void silu_grad_scaled(float zs, float& hs, float& g) {
-    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(zs));
-    hs = zs * s;
-    g = fmaf(hs, fmaf(s, kLn2, -kLn2), s);
-}
-__device__ __forceinline__ float silu(float z) {  // base net: unscaled
-    return z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -kLog2e));
-}
-
-// hi/lo split of an fp32 value into two fp16-representable fp32 values (see header comment)
-__device__ __forceinline__ float hi_part(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFFE000u); }
-
-// sin and cos of a bounded argument (|a| <~ 1e3; the encoder's arguments are 2^b y with |y| <= pi, b <= 4): Cody-Waite
-// reduction by pi/2 in four parts (8 + 11 + 11 bits + remainder: k * part is exact, so is the first subtraction) and
-// the Cephes single-precision kernels on [-pi/4, pi/4]; max abs error 9.2e-8 (numpy prototype vs fp64, 8 M
-// arguments in [-100, 100]) against 6.9e-8 of a correctly rounded fp32 sin.  ~24 VALU instead of the ~3x longer
-// general-argument sincosf (whose Payne-Hanek branch these arguments never take).
-__device__ __forceinline__ void sincos_bounded(float a, float& s_out, float& c_out) {
-    const float k = rintf(a * 0.6366197466850281f);
-    float r = fmaf(k, -1.5703125f, a);
-    r = fmaf(k, -0.0004837512969970703f, r);
-    r = fmaf(k, -7.549533620476723e-08f, r);
-    r = fmaf(k, -2.5633440682570896e-12f, r);
-    const float z = r * r;
-    float p = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
-    p = fmaf(p, z, -1.6666654611e-1f);
-    const float s = fmaf(p * z, r, r);
-    float q = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
-    q = fmaf(q, z, 4.166664568298827e-2f);
-    const float c = fmaf(q * z, z, fmaf(z, -0.5f, 1.0f));
-    const int n = (int)k;
-    const float ss = (n & 1) ? c : s, cc = (n & 1) ? s : c;
-    s_out = __uint_as_float(__float_as_uint(ss) ^ ((unsigned)(n & 2) << 30));
-    c_out = __uint_as_float(__float_as_uint(cc) ^ ((unsigned)((n + 1) & 2) << 30));
-}
-
-// The encoder's and the spherical net's sines / cosines: the bounded-argument kernel above, libm's sincosf only for
-// arguments the reference never produces.  Within-run A/B against sincosf everywhere (profiles/r02_ab/ab4): spherical
-// kernels -1.0 %, 64-wide -0.8 %, disk +-0 (noise); p99 pdf error unchanged on all seven golden sets.
-__device__ __forceinline__ void sincos_enc(float a, float& s, float& c) {
-    if (__builtin_expect(fabsf(a) <= 1024.0f, 1)) sincos_bounded(a, s, c);
-    else sincosf(a, &s, &c);
-}
-
-// LDS reads the compiler does not schedule or wait for: issued a phase ahead of their use and waited for just before the
-// first MFMA that consumes them (cdna_hip_programming.md §5.7, form (ii)).  hipcc itself places a ds_read right in front of
-// its use.  Until the wait statement the destination registers hold stale data although the compiler considers them defined:
-// whether the code in between leaves them alone depends on the toolchain's register allocation, so the BUILD checks it —
-// _lib.build() runs bsdf_diffusion_sampling_amd/_asmcheck.py on the assembly of the compilation it is about to ship and,
-// if any instruction touches a pending destination, recompiles this file with -DBSDFD_NO_ASYNC_LDS: the same reads as
-// ordinary loads the compiler schedules and waits for itself (~2 % slower, the round-3 `ab2_mim_first` form).
-#ifdef BSDFD_NO_ASYNC_LDS
-#define BSDFD_LDS_VARIANT "compiler-managed LDS reads (fallback build)"
-template <int OFF>
-__device__ __forceinline__ void lds_read_b128_async_at(f16x8& dst, unsigned lane_base) {
-    typedef const f16x8 __attribute__((address_space(3))) * lds_frag_ptr;
-    dst = *reinterpret_cast<lds_frag_ptr>(static_cast<uintptr_t>(lane_base + (unsigned)OFF));
-}
-#define BSDFD_WAIT2(after, a, b) ((void)0)
-#define BSDFD_WAIT4(after, a, b, c, d) ((void)0)
-#define BSDFD_WAIT5(after, a, b, c, d, e) ((void)0)
-#define BSDFD_WAIT6(after, a, b, c, d, e, f) ((void)0)
-#else
-#define BSDFD_LDS_VARIANT "asynchronous LDS reads"
-template <int OFF>
-__device__ __forceinline__ void lds_read_b128_async_at(f16x8& dst, unsigned lane_base) {  // address = lane_base + OFF (immediate)
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lane_base), "n"(OFF) : "memory");
-}
-// One wait statement names every destination of a batch as "+v": all consumers are ordered behind it.  `after` is a value
-// the wait is made to depend on as well (the B fragment the activation math of the layer produces): without it the compiler
-// schedules the wait — which depends on nothing else — right behind the reads, in front of the math that is meant to hide them.
-#define BSDFD_WAIT2(after, a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(after), "+v"(a), "+v"(b) : : "memory")
-#define BSDFD_WAIT4(after, a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(after), "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory")
-#define BSDFD_WAIT5(after, a, b, c, d, e) \
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(after), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : : "memory")
-#define BSDFD_WAIT6(after, a, b, c, d, e, f) \
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(after), "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : : "memory")
-#endif
-// hipcc's hazard recognizer pads the wait states between an MFMA and the first reader of its result (8 for the 4-pass
-// v_mfma_f32_16x16x32_f16, 10 for the 8-pass fp32 shapes: bsdf_diffusion_sampling_amd/_asmcheck.py), but where the MFMAs sit at the
-// BOTTOM of a run-time loop and the reader at its head it was found ONE state short on the path through the back edge (round 4,
-// every run-time-depth instantiation: 7 of 8 resp. 9 of 10; profiles/r04_ab/mfma_hazard_compiler_gap.txt).  One asm statement at
-// the loop head with two wait states inside that names the loop-carried MFMA results as operands, so that none of their readers
-// can be scheduled in front of it; _asmcheck verifies the shipped assembly with the strict numbers.
-template <int NM, bool JAC>
-__device__ __forceinline__ void loop_head_pad(f32x4 (&z)[NM], f32x4 (&a)[NM], f32x4 (&b)[NM]) {
-    static_assert(NM == 2 || NM == 4, "one operand list per width");
-    if constexpr (NM == 2 && JAC)
-        asm volatile("s_nop 1" : "+v"(z[0]), "+v"(z[1]), "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]));
-    else if constexpr (NM == 2)
-        asm volatile("s_nop 1" : "+v"(z[0]), "+v"(z[1]));
-    else if constexpr (JAC)
-        asm volatile("s_nop 1" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]),
-                     "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-    else
-        asm volatile("s_nop 1" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]));
-}
-union Frag {  // one MFMA B fragment: the lane's 8 K-values of a chunk
-    f16x8 v;
-    f16x2 p[4];
-};
-template <bool SPLIT>
-__device__ __forceinline__ void split_pack(const float (&x)[4], f16x2& h01, f16x2& h23, f16x2& l01, f16x2& l23) {
-    if (SPLIT) {
-        const float h0 = hi_part(x[0]), h1 = hi_part(x[1]), h2 = hi_part(x[2]), h3 = hi_part(x[3]);
-        h01 = (f16x2){(_Float16)h0, (_Float16)h1};
-        h23 = (f16x2){(_Float16)h2, (_Float16)h3};
-        l01 = (f16x2){(_Float16)(x[0] - h0), (_Float16)(x[1] - h1)};
-        l23 = (f16x2){(_Float16)(x[2] - h2), (_Float16)(x[3] - h3)};
-    } else {
-        h01 = (f16x2){(_Float16)x[0], (_Float16)x[1]};
-        h23 = (f16x2){(_Float16)x[2], (_Float16)x[3]};
-    }
-}
-
-__device__ __forceinline__ float sel4(int g, float a0, float a1, float a2, float a3) {
-    return g == 0 ? a0 : (g == 1 ? a1 : (g == 2 ? a2 : a3));
-}
-
-// Scalar functions of the per-query prologue / epilogue on the hardware transcendentals (round 4: libm's versions are a measurable
-// part of the ~100 us a 1 Mi-query spherical launch spends outside its Euler steps, tools/fixed_cost.py).  v_log_f32 / v_exp_f32 are
-// 1-ulp log2 / exp2: ln x = ln 2 * log2 x carries <= 2 ulp + 1e-7 |ln x|, far inside the 1e-4 contract (the density tests hold the
-// results to 2e-5 of the fp64 oracle).
-__device__ __forceinline__ float fast_log(float x) { return kLn2 * __builtin_amdgcn_logf(x); }
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }
-// acos on [-1, 1] for the von Mises SAMPLER only (Abramowitz & Stegun 4.4.46, |error| <= 2e-8 + the hardware sqrt's ulp): the
-// value is the sample itself — its density is evaluated at whatever comes out — so 1e-7 of absolute error is immaterial there.
-// (cart_to_spher keeps libm's acosf / atan2f: their error is amplified by the encoder's 2^4 and by the flow.)
-__device__ __forceinline__ float fast_acos(float x) {
-#pragma clang fp contract(off)
-    const float a = fabsf(x);
-    float p = -0.0012624911f;
-    p = fmaf(p, a, 0.0066700901f); p = fmaf(p, a, -0.0170881256f); p = fmaf(p, a, 0.0308918810f);
-    p = fmaf(p, a, -0.0501743046f); p = fmaf(p, a, 0.0889789874f); p = fmaf(p, a, -0.2145988016f);
-    p = fmaf(p, a, 1.5707963050f);
-    const float r = __builtin_amdgcn_sqrtf(fmaxf(1.0f - a, 0.0f)) * p;
-    return x < 0.0f ? 3.14159265358979323846f - r : r;
-}
-
-// cart_to_spher of the spherical plugins (rendering/brdf_measured_spherical.py:35-39): theta = acos(z / (r + 1e-8)), phi = atan2(y, x).
-// Evaluated as written, fp32 loses theta near the pole: the quotient is rounded to a multiple of 6e-8 and acos amplifies that by
-// 1 / sin(theta) — up to 6.5e-5 rad on the golden fixtures, which the encoder's 2^4 and the flow turn into 1.0e-4 (p99) of pdf error
-// on chm_orange: the reference's own fp32-vs-fp64 distance at plugin level.  The SAME angle in a well-conditioned form: with
-// r' = r + eps, cos(theta) = z / r' and sin(theta) = sqrt(r'^2 - z^2) / r' = sqrt(x^2 + y^2 + 2 r eps + eps^2) / r' (a sum of
-// non-negative terms), so theta = atan2(sqrt(x^2 + y^2 + 2 r eps + eps^2), z) — identical in real arithmetic, eps included (at
-// the pole both give sqrt(2 eps)), 1.5e-7 rad from the fp64 value on the same fixtures.  `ref_pole`: where the reference's fp32
-// quotient is not inside (-1, 1) its theta is 0, pi or NaN and its sin(theta) > 5e-5 guard zeroes the density: pdf() keeps that
-// decision (rendering/brdf_measured_spherical.py:134).
-//
-// Both angles are an atan2f of different arguments, and every lane of a query would evaluate them redundantly (~50 VALU
-// instructions each; a pdf() launch needs four: theta and phi of wi and of wo).  So the four lanes of a query take ONE angle
-// each - lane (g, q) evaluates job g & (NJ - 1) - and the results are handed round with ds_bpermute (the LDS crossbar, not
-// the VALU): bit-identical to the redundant evaluation, 150 VALU instructions per tile less in a spherical pdf() launch, 50 in a
-// sample() launch (tools/pro_count.sh counted 557 resp. 740 outside the Euler loop before).
-struct SphArgs {        // theta = atan2(s, z), phi = atan2(y, x)
-    float s, z, y, x;
-    bool ref_pole;
-};
-__device__ __forceinline__ SphArgs spher_args(float x, float y, float z) {
-    const float eps = 1e-8f;
-    const float s2 = x * x + y * y;
-    const float r = sqrtf(s2 + z * z);
-    SphArgs a;
-    a.s = sqrtf(s2 + (2.0f * r * eps + eps * eps));
-    a.z = z; a.y = y; a.x = x;
-    a.ref_pole = !(fabsf(z / (r + eps)) < 1.0f);
-    return a;
-}
-template <int NJ>   // NJ = 2 or 4 jobs (Y[k], X[k]); out[k] = atan2f(Y[k], X[k]) in every lane of the query
-__device__ __forceinline__ void atan2_by_lane(const float (&Y)[NJ], const float (&X)[NJ], int g, int q, float (&out)[NJ]) {
-    static_assert(NJ == 2 || NJ == 4, "jobs are dealt to the 4 lanes of a query");
-    const int j = g & (NJ - 1);
-    float yy = Y[0], xx = X[0];
-#pragma unroll
-    for (int k = 1; k < NJ; ++k) {
-        yy = j == k ? Y[k] : yy;
-        xx = j == k ? X[k] : xx;
-    }
-    const float a = atan2f(yy, xx);
-#pragma unroll
-    for (int k = 0; k < NJ; ++k) out[k] = __shfl(a, 16 * k + q, 64);   // row k of the wave holds job k
-}
-
-// log I0(kappa): the two polynomials of torch.distributions.von_mises._log_modified_bessel_fn
-// (torch 2.10; call site rendering/utils/model.py:314), split at 3.75.
-__device__ __forceinline__ float log_i0(float k) {
-    if (k < 3.75f) {
-        float y = k * (1.0f / 3.75f);
-        y = y * y;
-        float p = 0.0045813f;
-        p = fmaf(p, y, 0.0360768f); p = fmaf(p, y, 0.2659732f); p = fmaf(p, y, 1.2067492f);
-        p = fmaf(p, y, 3.0899424f); p = fmaf(p, y, 3.5156229f); p = fmaf(p, y, 1.0f);
-        return fast_log(p);
-    }
-    const float y = 3.75f * __builtin_amdgcn_rcpf(k);
-    float p = 0.00392377f;
-    p = fmaf(p, y, -0.01647633f); p = fmaf(p, y, 0.02635537f); p = fmaf(p, y, -0.02057706f);
-    p = fmaf(p, y, 0.00916281f); p = fmaf(p, y, -0.00157565f); p = fmaf(p, y, 0.00225319f);
-    p = fmaf(p, y, 0.01328592f); p = fmaf(p, y, 0.39894228f);
-    return k - 0.5f * fast_log(k) + fast_log(p);
-}
-
-__device__ __forceinline__ float softplus(float x) {  // nn.Softplus(beta=1, threshold=20)
-    // (1 + e^x loses e^x's low bits for x << 0: an ABSOLUTE error <= 6e-8 on kappa = softplus + 1e-3, i.e. <= 1.2e-7 on log p)
-    return x > 20.0f ? x : fast_log(1.0f + fast_exp(x));
-}
-
-// Best & Fisher rejection sampler for VonMises(mu, kappa)
-// (torch/distributions/von_mises.py::_rejection_sample; call site rendering/utils/model.py:305).
-// * Proposal constant: torch forms rho = (tau - sqrt(2 tau)) / (2 kappa) in fp64 because the difference
-//   cancels in fp32; here the rationalised form rho = 2 kappa / (tau + sqrt(2 tau)) (tau (tau - 2) =
-//   4 kappa^2) has no cancellation and is evaluated in fp32.  r only shapes the envelope — the
-//   accept test uses the same r, so the sampler is exact for any r > 1.
-// * The 4 lanes of a query (lane = 16 g + q) test 4 CONSECUTIVE proposals of the query's Philox
-//   stream at once (proposal index 4 round + g); the first accepted one in stream order wins, so the
-//   draw equals the sequential loop's while a wave needs ~1.2 rounds instead of ~3.5 (max over its
-//   16 queries of a geometric trip count with acceptance >= 0.66).
-__device__ __forceinline__ float von_mises_sample(float mu, float kappa, unsigned k0, unsigned k1, unsigned q_lo,
-                                                  unsigned q_hi, int lane) {
-    // No implicit fma contraction in here: the accept test is a comparison, and a product fused in one kernel instantiation but
-    // not in another would flip it for the occasional query — every instantiation (single-op, fused, segmented) must draw the
-    // same sample for the same Philox counter.
-#pragma clang fp contract(off)
-    float r;
-    // (hardware rcp / sqrt / log / cos and the polynomial acos: r only shapes the envelope, the accept test is a comparison of
-    //  random numbers, and the accepted angle is the sample itself — ulp-level differences change nothing statistically)
-    if (kappa < 1e-5f) {
-        r = __builtin_amdgcn_rcpf(kappa) + kappa;
-    } else {
-        const float tau = 1.0f + __builtin_amdgcn_sqrtf(1.0f + 4.0f * kappa * kappa);
-        const float rho = 2.0f * kappa * __builtin_amdgcn_rcpf(tau + __builtin_amdgcn_sqrtf(2.0f * tau));
-        r = (1.0f + rho * rho) * __builtin_amdgcn_rcpf(2.0f * rho);
-    }
-    const int g = lane >> 4, q = lane & 15;
-    float x = 0.0f;
-    bool done = false;
-    for (unsigned round = 0; round < 64u; ++round) {
-        unsigned u[4];
-        philox4x32(k0, k1, q_lo, q_hi, round * 4u + (unsigned)g + 1u, 0x564d6973u, u);  // "VMis"
-        const float u1 = u01_open(u[0]), u2 = u01_open(u[1]), u3 = u01_open(u[2]);
-        const float z = __builtin_amdgcn_cosf(0.5f * u1);   // v_cos_f32 takes revolutions: cos(pi u1)
-        const float f = (1.0f + r * z) * __builtin_amdgcn_rcpf(r + z);
-        const float c = kappa * (r - f);
-        const bool accept = (c * (2.0f - c) - u2 > 0.0f) || (fast_log(c * __builtin_amdgcn_rcpf(u2)) + 1.0f - c >= 0.0f);
-        const float a = fast_acos(fminf(fmaxf(f, -1.0f), 1.0f));
-        const float cand = (u3 - 0.5f) < 0.0f ? -a : a;
-        const unsigned long long acc_mask = __builtin_amdgcn_ballot_w64(accept);
-        const unsigned long long mine = (acc_mask >> q) & 0x0001000100010001ull;  // bit 16 g' = lane (g', q)
-        const int first_g = mine ? (__builtin_ctzll(mine) >> 4) : 0;
-        const float got = __shfl(cand, first_g * 16 + q, 64);
-        if (!done && mine) { x = got; done = true; }
-        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
-    }
-    const float two_pi = 6.28318530717958647692f, pi = 3.14159265358979323846f;
-    const float t = x + pi + mu;
-    float w = fmaf(-two_pi, floorf(t * (1.0f / two_pi)), t);   // t mod 2 pi, in [0, 2 pi) up to rounding
-    if (w < 0.0f) w += two_pi;
-    if (w >= two_pi) w -= two_pi;
-    return w - pi;
-}
 
 // ---------------------------------------------------------------------------------------------
 // The fused flow kernel.
@@ -1512,6 +1164,12 @@ struct bsdfd_ctx {
     const void* kfun[3];
     ImgLayout L;
     char* d_img;
+    // 32-query-tile kernels (flow32.hip): which modes run them, and their weight image.  tile[m] = queries per wave tile of
+    // mode m's kernel (16 | 32), img_of[m] / img_bytes[m] = the image that kernel reads (= its dynamic LDS)
+    char* d_img32;
+    int tile[3];
+    const char* img_of[3];
+    int img_bytes[3];
     // profiling: a ring of HIP event pairs recorded on the launch stream around every launch.  Everything
     // above this line is immutable after create; the profiling state below is guarded by `prof_mu`, so the
     // handle stays re-entrant across host threads / streams with profiling on (launches that are being timed
@@ -1764,6 +1422,8 @@ const void* kernel_ptr(int domain, int nm, int n_hidden, int prec, int mode) {
     return kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 4, 0>(prec, mode);
 }
 inline int threads_for(int nm) { return nm == 2 ? 256 : 512; }
+// queries per wave tile of the Jacobian kernels when the caller leaves bsdfd_desc.tile at 0 and $BSDFD_TILE is unset
+constexpr int kDefaultTile = 16;
 // extra dynamic LDS per workgroup: 0 in the product; a tools build (tools/tuning_knobs.h) reads $BSDFD_LDS_PAD to lower the
 // number of resident workgroups per CU (occupancy sweeps of the same binary)
 #ifdef BSDFD_TOOLS_LDS_PAD
@@ -1835,7 +1495,7 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     if (dev != h->device) return fail(BSDFD_EINVAL, "handle was created on device " + std::to_string(h->device) +
                                                         " but device " + std::to_string(dev) + " is current");
     KParams kp;
-    kp.img = h->d_img; kp.L = h->L;
+    kp.L = h->L;
     kp.in_a = in_a; kp.in_b = in_b; kp.out_x = out_x; kp.out_pdf = out_pdf;
     kp.in_c = in_c; kp.out_pdf2 = out_pdf2;
     kp.N = N; kp.T = T; kp.n_hidden = h->n_hidden; kp.op = op; kp.io = io; kp.seed = seed; kp.offset = offset;
@@ -1851,6 +1511,9 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     // instantiated kernel: VGPR- or LDS-limited); block-granular dynamic balancing measured ~4 %
     // faster than an exactly-resident persistent grid (tools/tscan.py sweep)
     const int mode = op == OP_SAMPLES_ONLY ? 0 : (op == OP_SAMPLE_PDF ? 2 : 1);
+    kp.img = h->img_of[mode];
+    kp.L.total = h->img_bytes[mode];
+    const int tile = h->tile[mode];
     int per_cu = h->per_cu[mode];
     if (per_cu < 1) per_cu = 1;
     // grid-shape overrides of the tools builds (tools/tuning_knobs.h, force-included by tools/ab_build.sh for tools/tscan.py
@@ -1870,7 +1533,7 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     };
     long long nblocks;
     if (!segs) {
-        const long long ntiles = (N + 15) / 16;
+        const long long ntiles = (N + tile - 1) / tile;
         kp.chunk_log2 = pick_cl(ntiles, 8LL * h->num_cu);
         const long long want = (ntiles + ((long long)waves << kp.chunk_log2) - 1) / ((long long)waves << kp.chunk_log2);
         nblocks = want < cap ? want : cap;
@@ -1879,7 +1542,7 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
         long long total_want = 0;
         std::vector<long long> want(segs->size());
         for (size_t i = 0; i < segs->size(); ++i) {
-            const long long nt = ((*segs)[i].q_end - (*segs)[i].q_begin + 15) / 16;
+            const long long nt = ((*segs)[i].q_end - (*segs)[i].q_begin + tile - 1) / tile;
             want[i] = (nt + waves - 1) / waves;
             total_want += want[i];
         }
@@ -1890,13 +1553,13 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
             if (nb < 1) nb = 1;
             if (nb > want[i]) nb = want[i];
             KParams::Seg& sg = kp.seg[kp.nseg++];
-            sg.img = (*segs)[i].h->d_img;
+            sg.img = (*segs)[i].h->img_of[mode];
             sg.q_begin = (*segs)[i].q_begin;
             sg.q_end = (*segs)[i].q_end;
             sg.blk_begin = b;
             b += (int)nb;
             sg.blk_end = b;
-            sg.chunk_log2 = pick_cl(((*segs)[i].q_end - (*segs)[i].q_begin + 15) / 16, 8LL * nb);
+            sg.chunk_log2 = pick_cl(((*segs)[i].q_end - (*segs)[i].q_begin + tile - 1) / tile, 8LL * nb);
             sg.pad = 0;
         }
         nblocks = b;
@@ -1915,7 +1578,7 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
             HIP_TRY(hipEventRecord(h->ev0[slot], s));
         }
     }
-    hipError_t e = hipLaunchKernel(h->kfun[mode], grid, block, args, (size_t)h->L.total + lds_pad(), s);
+    hipError_t e = hipLaunchKernel(h->kfun[mode], grid, block, args, (size_t)h->img_bytes[mode] + lds_pad(), s);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) return fail(BSDFD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     if (slot >= 0) {
@@ -1935,9 +1598,10 @@ int run_multi(const bsdfd_handle* hs, int n, const int64_t* seg_end, int op, int
     for (int i = 0; i < n; ++i) {
         if (!hs[i]) return fail(BSDFD_EINVAL, "null handle in the table");
         if (hs[i]->domain != hs[0]->domain || hs[i]->width != hs[0]->width || hs[i]->n_hidden != hs[0]->n_hidden ||
-            hs[i]->precision != hs[0]->precision || hs[i]->device != hs[0]->device)
+            hs[i]->precision != hs[0]->precision || hs[i]->device != hs[0]->device || hs[i]->tile[1] != hs[0]->tile[1] ||
+            hs[i]->tile[2] != hs[0]->tile[2])
             return fail(BSDFD_EINVAL, "handles of one multi-material launch must share domain, width, depth, "
-                                      "precision and device");
+                                      "precision, tile and device");
         if (seg_end[i] < (i ? seg_end[i - 1] : 0)) return fail(BSDFD_EINVAL, "segment ends must be non-decreasing");
     }
     const int64_t N = seg_end[n - 1];
@@ -1974,6 +1638,7 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     if (!d->w_in || !d->w_out || !d->base_w1 || !d->base_b1 || !d->base_w2 || !d->base_b2 ||
         (d->n_hidden > 1 && !d->w_hidden))
         return fail(BSDFD_EINVAL, "null weight pointer");
+    if (d->tile != 0 && d->tile != 16 && d->tile != 32) return fail(BSDFD_EINVAL, "tile must be 0 (default), 16 or 32");
     int prec = d->precision == BSDFD_PREC_DEFAULT ? BSDFD_PREC_SPLIT3 : d->precision;
     if (prec != BSDFD_PREC_F32 && prec != BSDFD_PREC_SPLIT3 && prec != BSDFD_PREC_F16)
         return fail(BSDFD_EINVAL, "unknown precision");
@@ -1988,7 +1653,7 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     h->state_dim = d->domain == BSDFD_DOMAIN_DISK ? 2 : 3;
     h->in_dim = h->state_dim + 1 + 2 + 4 * PE_BANDS;
     h->device = dev; h->num_cu = prop.multiProcessorCount;
-    h->profiling = false; h->d_img = nullptr; h->d_clk = nullptr;
+    h->profiling = false; h->d_img = nullptr; h->d_img32 = nullptr; h->d_clk = nullptr;
     h->n_rec = h->n_done = 0; h->total_ms = 0.0; h->last_ms = -1.0f;
     for (int i = 0; i < 4; ++i) { h->n_op[i] = 0; h->ms_op[i] = 0.0; }
     {
@@ -2007,6 +1672,22 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_img), img.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_img, img.data(), img.size(), hipMemcpyHostToDevice);
+    // Tile of the Jacobian kernels: desc->tile (0 = the library's default, which $BSDFD_TILE overrides: A/B runs of one build).
+    // The 32-query-tile kernels exist for the reference's two plugin nets in split3 only; everything else runs 16-query tiles.
+    int want_tile = d->tile;
+    if (want_tile == 0) {
+        const char* ev = std::getenv("BSDFD_TILE");
+        want_tile = ev ? std::atoi(ev) : kDefaultTile;
+    }
+    const bool t32 = want_tile == 32 && bsdfd_tile32_supported(*d, prec);
+    for (int m = 0; m < 3; ++m) { h->tile[m] = 16; h->img_of[m] = h->d_img; h->img_bytes[m] = h->L.total; }
+    if (t32 && e == hipSuccess) {
+        const std::vector<char> img32 = bsdfd_build_image32(*d);
+        e = hipMalloc(reinterpret_cast<void**>(&h->d_img32), img32.size());
+        if (e == hipSuccess) e = hipMemcpy(h->d_img32, img32.data(), img32.size(), hipMemcpyHostToDevice);
+        for (int m = 1; m < 3; ++m)
+            if (bsdfd_kernel32(h->domain, m)) { h->tile[m] = 32; h->img_of[m] = h->d_img32; h->img_bytes[m] = (int)img32.size(); }
+    }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_clk), (size_t)CLK_SLOTS * 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->d_clk, 0, (size_t)CLK_SLOTS * 8 * sizeof(unsigned long long));
     for (int i = 0; i < bsdfd_ctx::RING && e == hipSuccess; ++i) {
@@ -2014,16 +1695,17 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
         if (e == hipSuccess) e = hipEventCreate(&h->ev1[i]);
     }
     for (int jac = 0; jac < 3 && e == hipSuccess; ++jac) {
-        h->kfun[jac] = kernel_ptr(h->domain, h->width / 16, h->n_hidden, prec, jac);
+        h->kfun[jac] = h->tile[jac] == 32 ? bsdfd_kernel32(h->domain, jac) : kernel_ptr(h->domain, h->width / 16, h->n_hidden, prec, jac);
         // dynamic LDS above the default cap needs the attribute (per function and device)
-        e = hipFuncSetAttribute(h->kfun[jac], hipFuncAttributeMaxDynamicSharedMemorySize, h->L.total + (int)lds_pad());
+        e = hipFuncSetAttribute(h->kfun[jac], hipFuncAttributeMaxDynamicSharedMemorySize, h->img_bytes[jac] + (int)lds_pad());
         int nb = 0;
         if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h->kfun[jac], threads_for(h->width / 16), (size_t)h->L.total + lds_pad());
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h->kfun[jac], threads_for(h->width / 16), (size_t)h->img_bytes[jac] + lds_pad());
         h->per_cu[jac] = nb;
     }
     if (e != hipSuccess) {
         if (h->d_img) (void)hipFree(h->d_img);
+        if (h->d_img32) (void)hipFree(h->d_img32);
         if (h->d_clk) (void)hipFree(h->d_clk);
         for (int i = 0; i < bsdfd_ctx::RING; ++i) {
             if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
@@ -2079,6 +1761,7 @@ int bsdfd_create_from_file(const char* path, int32_t precision, bsdfd_handle* ou
 void bsdfd_destroy(bsdfd_handle h) {
     if (!h) return;
     if (h->d_img) (void)hipFree(h->d_img);
+    if (h->d_img32) (void)hipFree(h->d_img32);
     if (h->d_clk) (void)hipFree(h->d_clk);
     for (int i = 0; i < bsdfd_ctx::RING; ++i) {
         (void)hipEventDestroy(h->ev0[i]);
@@ -2134,7 +1817,9 @@ int bsdfd_plugin_pdf(bsdfd_handle h, int32_t variant, const float* wi, const flo
 
 int64_t bsdfd_context_bytes(bsdfd_handle h, int64_t N, int32_t n_segments) {
     if (!h || N < 0 || n_segments < 1) return -1;
-    const int64_t per_tile = ((int64_t)(h->width / 16) * 64 + 16) * 16;  // cacc[NM] per lane + bo per query, 16 B each
+    // per 16-query tile: cacc[NM] per lane + bo per query, 16 B each; the 32-query-tile kernels store (4 x 64 + 32) x 16 B per tile
+    if (h->tile[1] == 32) return ((N + 31) / 32 + n_segments) * (int64_t)((4 * 64 + 32) * 16);
+    const int64_t per_tile = ((int64_t)(h->width / 16) * 64 + 16) * 16;
     return ((N + 15) / 16 + n_segments) * per_tile;
 }
 

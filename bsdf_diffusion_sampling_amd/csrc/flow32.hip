@@ -1,0 +1,726 @@
+// flow32.hip — the flow sampler on 32-QUERY TILES: the two nets the reference's plugins load (disk 25-32x3-2,
+// rendering/utils/model.py:479-501; spherical 26-32x4-2, :422-446; split-fp16 arithmetic) on v_mfma_f32_32x32x16_f16.
+//
+// Why a second tiling: in the VALU-heavy instruction stream of the Euler step a v_mfma_f32_16x16x32_f16 hides
+// NO other work (its 16 matrix-pipe cycles add to the VALU time), a 32x32x16 lets ~9 cycles of the co-resident waves' VALU work
+// through per instruction (tools/ubench/mfma_src, profiles/r04_ab/mfma_shapes_ubench.txt).  The 32-wide nets fit the shape exactly:
+// M = 32 = all hidden units, N = 32 queries, two K = 16 chunks per contraction — no padded rows in the hidden layers.
+//
+// Mapping (compare bsdfd.hip's header):
+//   * a wave64 owns 32 queries; lane = (h = lane >> 5, n = lane & 31) holds, for query n, the 16 hidden units
+//     u(v, h) = 8 (v >> 2) + 4 h + (v & 3), v = 0..15 — the C/D layout of the 32x32 shapes.  The K index of the next contraction
+//     is permuted to match (chunk c, lane half h, slot j  <->  unit u(8 c + j, h); the host packs the A fragments accordingly),
+//     so the lane's accumulator registers 8c .. 8c+7, split hi/lo and packed, ARE the B fragment of chunk c: activations never
+//     leave registers between layers.
+//   * the query's state is DISTRIBUTED over its two lanes: lane h = 0 carries x0 (theta), lane h = 1 carries x1 (phi).  Layer 1
+//     is ONE fp16 MFMA per step: the B slots of a lane are [v_hi, v_lo, v_hi, w_hi, w_lo, w_hi, 0, 0] with (v, w) = (x0, alpha) |
+//     (x1, 0) (disk) or (theta, alpha) | (sin phi, cos phi) (spherical), the A slots [W_hi, W_hi, W_lo] of the matching columns of
+//     W1 (hi hi + hi lo + lo hi inside one instruction), C-in = the per-query conditioning term.
+//   * the two-row output layer is an fp32 VALU dot over the lane's 16 units (the last hidden activation is never split) and one
+//     v_permlane32_swap, which leaves v0 in the lower and v1 in the upper half-wave: exactly where x0 and x1 live.
+//   * the Jacobian meets in the middle as in the 16-query kernels (MIM / MIMS); its reduction runs over the 2 lanes of a query
+//     (4 swaps per 32 queries instead of 5 per 16).
+//   * per-tile prologue: lane h encodes dimension h of omega_i (5 sincos), the conditioning term is 6 split-fp16 MFMAs (disk) or
+//     11 exact-fp32 v_mfma_f32_32x32x2_f32 (spherical), the base net's first layer 7 exact-fp32 MFMAs, its second layer VALU.
+// Same operators, same plugin variants, same context / rng_index / segmented-launch semantics as the 16-query kernels; the base
+// draws are bit-identical to theirs (same Philox counters, same arithmetic).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "bsdfd.h"
+#include "common.h"
+#include "flow_dev.h"
+#include "flow32.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int FR32 = 64 * 16;  // bytes of one A fragment (32 rows x 16 K-values of fp16)
+
+// byte offsets into the weight image — compile-time constants per domain (the host's build_image32 uses the same struct)
+template <int DOMAIN>
+struct L32 {
+    static constexpr bool SPH = DOMAIN == BSDFD_DOMAIN_SPHERICAL;
+    static constexpr int NH = SPH ? 4 : 3;
+    static constexpr int A1 = 0;                                   // layer-1 state fragment
+    static constexpr int WT0 = A1 + FR32;                          // spherical: W1[:, theta] in accumulator layout, 64 lanes x 16 floats
+    static constexpr int WC = WT0 + (SPH ? 64 * 64 : 0);           // conditioning: disk 4 fragments (hi c0, hi c1, lo c0, lo c1); spherical 11 x 64 floats
+    static constexpr int WH = WC + (SPH ? 11 * 256 : 4 * FR32);    // hidden matrices W2 .. W_NH: 4 fragments each
+    static constexpr int WF = WH + (NH - 1) * 4 * FR32;            // disk: F0, F1 = W2 diag(W1[:, i])
+    static constexpr int WG = WF + (SPH ? 0 : 8 * FR32);           // G0, G1 = W_NH^T diag(Wout[j, :])
+    static constexpr int WOUT = WG + 8 * FR32;                     // 2 halves x 16 x (Wout[0][u], Wout[1][u]) floats
+    static constexpr int BW1 = WOUT + 256;                         // base net layer 1: 7 x 64 floats (A operands of the 32x32x2 MFMA)
+    static constexpr int BB1 = BW1 + 7 * 256;                      // 2 halves x 8 floats
+    static constexpr int BW2 = BB1 + 64;                           // 2 halves x 8 units x 4 outputs
+    static constexpr int BB2 = BW2 + 256;                          // 4 floats
+    static constexpr int TOTAL = BB2 + 16;
+};
+
+__host__ __device__ constexpr int unit32(int v, int h) { return 8 * (v >> 2) + 4 * h + (v & 3); }
+
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32f(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// v_permlane32_swap(x, y): x[32..63] <-> y[0..31].  Afterwards x + y is, in the lower half-wave, x summed over the lane pair
+// (l, l + 32) and, in the upper half, y summed over it.
+__device__ __forceinline__ void swap32(float& x, float& y) {
+    const auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(t[0]);
+    y = __uint_as_float(t[1]);
+}
+// both halves get (lower's value, upper's value) of a register
+__device__ __forceinline__ void both32(float x, float& lo, float& up) {
+    lo = x; up = x;
+    swap32(lo, up);
+}
+
+// the lane's 16 values of a vector -> the B fragments (hi, lo) of the two K = 16 chunks of the next contraction
+__device__ __forceinline__ void split16(const float (&x)[16], Frag (&hi)[2], Frag (&lo)[2]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float x4[4] = {x[8 * c + 4 * k], x[8 * c + 4 * k + 1], x[8 * c + 4 * k + 2], x[8 * c + 4 * k + 3]};
+            split_pack<true>(x4, hi[c].p[2 * k], hi[c].p[2 * k + 1], lo[c].p[2 * k], lo[c].p[2 * k + 1]);
+        }
+}
+
+// acc (+)= (W_hi + W_lo) (x_hi + x_lo) without the lo lo term; the matrix' 4 fragments (hi c0, hi c1, lo c0, lo c1) at `m`
+struct Mat32 {
+    f16x8 h0, h1, l0, l1;
+};
+__device__ __forceinline__ Mat32 load_mat(const char* smem, int off, int lane) {
+    const f16x8* m = reinterpret_cast<const f16x8*>(smem + off) + lane;
+    Mat32 r;
+    r.h0 = m[0]; r.h1 = m[64]; r.l0 = m[128]; r.l1 = m[192];
+    return r;
+}
+
+// Best & Fisher rejection sampler, 32-query tiles: the 2 lanes of a query test 4 consecutive proposals of the query's Philox
+// stream per round (lane h: proposals 4 round + 2 h + {0, 1}); the first accepted one in stream order wins, so the draw equals
+// von_mises_sample's (flow_dev.h) and the sequential loop's of torch/distributions/von_mises.py::_rejection_sample.
+__device__ __forceinline__ float von_mises_sample32(float mu, float kappa, unsigned k0, unsigned k1, unsigned q_lo, unsigned q_hi,
+                                                    int lane) {
+#pragma clang fp contract(off)
+    float r;
+    if (kappa < 1e-5f) {
+        r = __builtin_amdgcn_rcpf(kappa) + kappa;
+    } else {
+        const float tau = 1.0f + __builtin_amdgcn_sqrtf(1.0f + 4.0f * kappa * kappa);
+        const float rho = 2.0f * kappa * __builtin_amdgcn_rcpf(tau + __builtin_amdgcn_sqrtf(2.0f * tau));
+        r = (1.0f + rho * rho) * __builtin_amdgcn_rcpf(2.0f * rho);
+    }
+    const int h = lane >> 5, n = lane & 31;
+    float x = 0.0f;
+    bool done = false;
+    for (unsigned round = 0; round < 64u; ++round) {
+        bool has = false;
+        float mine = 0.0f;
+#pragma unroll
+        for (unsigned e = 0; e < 2u; ++e) {
+            unsigned u[4];
+            philox4x32(k0, k1, q_lo, q_hi, round * 4u + 2u * (unsigned)h + e + 1u, 0x564d6973u, u);  // "VMis"
+            const float u1 = u01_open(u[0]), u2 = u01_open(u[1]), u3 = u01_open(u[2]);
+            const float z = __builtin_amdgcn_cosf(0.5f * u1);
+            const float f = (1.0f + r * z) * __builtin_amdgcn_rcpf(r + z);
+            const float c = kappa * (r - f);
+            const bool accept = (c * (2.0f - c) - u2 > 0.0f) || (fast_log(c * __builtin_amdgcn_rcpf(u2)) + 1.0f - c >= 0.0f);
+            const float a = fast_acos(fminf(fmaxf(f, -1.0f), 1.0f));
+            const float cand = (u3 - 0.5f) < 0.0f ? -a : a;
+            if (!has && accept) { mine = cand; has = true; }
+        }
+        const unsigned long long acc_mask = __builtin_amdgcn_ballot_w64(has);
+        const bool lo_has = (acc_mask >> n) & 1ull, up_has = (acc_mask >> (n + 32)) & 1ull;
+        const float got = __shfl(mine, lo_has ? n : n + 32, 64);
+        if (!done && (lo_has || up_has)) { x = got; done = true; }
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;
+    }
+    const float two_pi = 6.28318530717958647692f, pi = 3.14159265358979323846f;
+    const float t = x + pi + mu;
+    float w = fmaf(-two_pi, floorf(t * (1.0f / two_pi)), t);
+    if (w < 0.0f) w += two_pi;
+    if (w >= two_pi) w -= two_pi;
+    return w - pi;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The kernel.  DOMAIN: BSDFD_DOMAIN_*; FUSED: the two-phase OP_SAMPLE_PDF loop (its own instantiation).
+// 2 waves per SIMD (256 VGPRs): per lane the step keeps 16-register vectors where the 16-query kernels keep 8.
+// ---------------------------------------------------------------------------------------------
+template <int DOMAIN, bool FUSED>
+__global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
+    using LY = L32<DOMAIN>;
+    constexpr bool SPH = DOMAIN == BSDFD_DOMAIN_SPHERICAL;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (p.clk) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+    const char* img = p.img;
+    long long q_begin = 0, q_end = p.N;
+    int blk = blockIdx.x, nblk = gridDim.x, cl = p.chunk_log2;
+    int sidx = 0;
+    if (p.nseg > 0) {
+        for (int i = 1; i < p.nseg; ++i)
+            if ((int)blockIdx.x >= p.seg[i].blk_begin) sidx = i;
+        img = p.seg[sidx].img;
+        q_begin = p.seg[sidx].q_begin;
+        q_end = p.seg[sidx].q_end;
+        blk = blockIdx.x - p.seg[sidx].blk_begin;
+        nblk = p.seg[sidx].blk_end - p.seg[sidx].blk_begin;
+        cl = p.seg[sidx].chunk_log2;
+    }
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(img);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = threadIdx.x; i < LY::TOTAL / 16; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 5;
+    const int n = lane & 31;
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    const double invT_d = 1.0 / (double)p.T;
+    const bool t_pow2 = (p.T & (p.T - 1)) == 0;
+    const float invT = (float)invT_d;
+    const int nphase = FUSED ? 2 : 1;
+    const bool reverse1 = (p.op == OP_PDF);
+    const float cstep1 = reverse1 ? -invT : invT;
+    const long long ntiles = (q_end - q_begin + 31) / 32;
+
+    // tile -> wave map: as in the 16-query kernels (chunks of 2^cl x waves_per_block consecutive tiles, round-robin over the grid)
+    const long long chunk = (long long)waves_per_block << cl;
+    for (long long it = 0;; ++it) {
+        const long long chunk_base = ((it >> cl) * nblk + blk) * chunk;
+        if (chunk_base >= ntiles) break;
+        const long long tile = chunk_base + (it & ((1 << cl) - 1)) * waves_per_block + wave;
+        if (tile >= ntiles) continue;
+        const long long qi_raw = q_begin + tile * 32 + n;
+        const bool valid = qi_raw < q_end;
+        const long long qi = valid ? qi_raw : q_end - 1;
+
+        // ---------------- inputs ---------------------------------------------------------------------
+        // yh: this lane's coordinate of the condition omega_i (lane h encodes dimension h); xs: this lane's coordinate of the
+        // point the flow starts from (pdf: omega_o; sample with an injected base point: x0)
+        float yh = 0.f, wi_z = 1.0f;
+        float xs = 0.f, wo_z = 1.0f, wo_sin = 1.0f;
+        float xo0 = 0.f, xo1 = 0.f;   // both coordinates of an injected / asked point (base density, epilogue)
+        bool wo_pole = false;
+        float xi0 = 0.f, xi1 = 0.f;   // FUSED: injected x0
+        const bool have_ctx = !FUSED && p.ctx_in != nullptr;
+        auto load_dir = [&](const float* dir) {   // plugin io: the direction whose pdf is asked -> start point of the reverse flow
+            const float ox = dir[qi * 3 + 0], oy = dir[qi * 3 + 1], oz = dir[qi * 3 + 2];
+            wo_z = oz;
+            wo_sin = sqrtf(ox * ox + oy * oy);  // Mitsuba Frame3f::sin_theta
+            if (!SPH) {
+                xs = h ? oy : ox;
+            } else {   // cart_to_spher (flow_dev.h: spher_args): lane h = 0 evaluates theta, lane h = 1 phi — one atan2f each
+                const SphArgs ao = spher_args(ox, oy, oz);
+                wo_pole = ao.ref_pole;
+                xs = atan2f(h ? ao.y : ao.s, h ? ao.x : ao.z);
+            }
+        };
+        if (p.io == IO_OPERATOR) {
+            const float2 c2 = reinterpret_cast<const float2*>(p.in_a)[qi];
+            yh = h ? c2.y : c2.x;
+            if (p.op == OP_PDF || p.in_b != nullptr) {
+                const float2 b2 = reinterpret_cast<const float2*>(p.in_b)[qi];
+                xs = h ? b2.y : b2.x;
+                xo0 = b2.x; xo1 = b2.y;
+            }
+        } else {
+            const float wx = p.in_a[qi * 3 + 0], wy = p.in_a[qi * 3 + 1], wz = p.in_a[qi * 3 + 2];
+            wi_z = wz;
+            if (!SPH) {
+                yh = h ? wy : wx;  // rendering/brdf_measured_disk.py:66-67
+            } else if (!have_ctx) {
+                const SphArgs ai = spher_args(wx, wy, wz);  // rendering/brdf_measured_spherical.py:35-39
+                yh = atan2f(h ? ai.y : ai.s, h ? ai.x : ai.z);
+            }
+            if (!FUSED && p.op == OP_PDF) load_dir(p.in_b);
+            if ((FUSED || p.op != OP_PDF) && p.in_b != nullptr) {  // injected base sample
+                const float2 b2 = reinterpret_cast<const float2*>(p.in_b)[qi];
+                if (FUSED) { xi0 = b2.x; xi1 = b2.y; } else { xs = h ? b2.y : b2.x; xo0 = b2.x; xo1 = b2.y; }
+            }
+        }
+
+        f32x16 cacc;
+        f32x4 bo;
+        constexpr long long CTX_V4 = 4 * 64 + 32;  // f32x4 per tile: cacc (4 per lane) + bo per query
+        const long long ctx_slot = ((q_begin + tile * 32) >> 5) + p.seg_base + sidx;
+        if (have_ctx) {
+            const f32x4* c = reinterpret_cast<const f32x4*>(p.ctx_in) + ctx_slot * CTX_V4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 t4 = c[k * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cacc[4 * k + r] = t4[r];
+            }
+            bo = c[4 * 64 + n];
+        } else {
+            // ---------------- positional encoding: lane h encodes dimension h ----------------------------
+            // e[2 b + fn] = fn(2^b y_h), fn = sin, cos; e[10] = y_h  (rendering/utils/model.py:26-57)
+            float e[11];
+#pragma unroll
+            for (int b = 0; b < PE_BANDS; ++b) sincos_enc(yh * (float)(1 << b), e[2 * b], e[2 * b + 1]);
+            e[10] = yh;
+            // ---------------- conditioning term c = W1[:, PE] PE(omega_i) -----------------------------
+            if (!SPH) {   // split-fp16: the lane's 11 values are K slots of two K = 16 chunks (the 16-query kernels' SPLIT_PRO)
+                const float e16[16] = {e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8], e[9], e[10], 0.f, 0.f, 0.f, 0.f, 0.f};
+                Frag eh[2], el[2];
+                split16(e16, eh, el);
+                const Mat32 wc = load_mat(smem, LY::WC, lane);
+                cacc = mfma32(wc.h0, eh[0].v, zero16);
+                cacc = mfma32(wc.h1, eh[1].v, cacc);
+                cacc = mfma32(wc.h0, el[0].v, cacc);
+                cacc = mfma32(wc.h1, el[1].v, cacc);
+                cacc = mfma32(wc.l0, eh[0].v, cacc);
+                cacc = mfma32(wc.l1, eh[1].v, cacc);
+            } else {      // exact fp32 chains (the spherical nets keep them: bsdfd.hip, SPLIT_PRO)
+                const float* Lwc = reinterpret_cast<const float*>(smem + LY::WC);
+                cacc = zero16;
+#pragma unroll
+                for (int j = 0; j < 11; ++j) cacc = mfma32f(Lwc[j * 64 + lane], e[j], cacc);
+            }
+            // ---------------- base-density net PE_3 -> 16 (SiLU) -> 4, exact fp32 -------------------------
+            {
+                const float* Lbw1 = reinterpret_cast<const float*>(smem + LY::BW1);
+                const f32x4* Lbb1 = reinterpret_cast<const f32x4*>(smem + LY::BB1 + h * 32);
+                const f32x4 b0 = Lbb1[0], b1 = Lbb1[1];
+                f32x16 bz = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const float be[7] = {yh, e[0], e[1], e[2], e[3], e[4], e[5]};
+#pragma unroll
+                for (int j = 0; j < 7; ++j) bz = mfma32f(Lbw1[j * 64 + lane], be[j], bz);
+                // (the wait states behind the last MFMA are spelled out: see the note at the base net in bsdfd.hip)
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(bz));
+                const f32x4* Lbw2 = reinterpret_cast<const f32x4*>(smem + LY::BW2 + h * 128);
+                f32x4 po = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int v = 0; v < 8; ++v) po += silu(bz[v]) * Lbw2[v];
+                // sum over the query's two lanes; every lane needs all four outputs
+                float o0 = po[0], o1 = po[1], o2 = po[2], o3 = po[3];
+                swap32(o0, o1);
+                swap32(o2, o3);
+                float s01 = o0 + o1, s23 = o2 + o3;   // lower: out0, out2 | upper: out1, out3
+                float a0, a1, a2, a3;
+                both32(s01, a0, a1);
+                both32(s23, a2, a3);
+                const f32x4 b2 = *reinterpret_cast<const f32x4*>(smem + LY::BB2);
+                bo = (f32x4){a0 + b2[0], a1 + b2[1], a2 + b2[2], a3 + b2[3]};
+            }
+            if (!FUSED && p.ctx_out != nullptr) {
+                f32x4* c = reinterpret_cast<f32x4*>(p.ctx_out) + ctx_slot * CTX_V4;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) c[k * 64 + lane] = (f32x4){cacc[4 * k], cacc[4 * k + 1], cacc[4 * k + 2], cacc[4 * k + 3]};
+                if (h == 0) c[4 * 64 + n] = bo;
+            }
+        }
+        // bo = (loc0, loc1, ls0, ls1) disk | (loc, log_scale, mu, kappa_raw) spherical
+        float kappa = 0.0f;
+        if (SPH) kappa = softplus(bo[3]) + 1e-3f;
+
+        int ph = 0;
+    next_phase:
+        {
+        const int op = FUSED ? (ph ? OP_PDF : OP_SAMPLE) : p.op;
+        const bool reverse = FUSED ? (ph != 0) : reverse1;
+        const float cstep = FUSED ? (ph ? -invT : invT) : cstep1;
+        float* const out_pdf = (FUSED && ph) ? p.out_pdf2 : p.out_pdf;
+        if (FUSED && ph) load_dir(p.in_c);
+        if (FUSED && !ph) { xs = h ? xi1 : xi0; xo0 = xi0; xo1 = xi1; }
+        // ---------------- initial state ------------------------------------------------------------
+        auto fexp = [](float x) -> float { return __builtin_amdgcn_exp2f(x * kLog2e); };
+        if (op == OP_SAMPLE && p.in_b == nullptr) {  // draw x0 ~ D_base(. | omega_i): same counters and arithmetic as bsdfd.hip
+            const unsigned long long ctr = p.offset + (unsigned long long)(p.rng_index ? p.rng_index[qi] : qi);
+            const unsigned k0 = (unsigned)p.seed, k1 = (unsigned)(p.seed >> 32);
+            unsigned u[4];
+            philox4x32(k0, k1, (unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0x476175u, u);  // "Gau"
+            const float rad = __builtin_amdgcn_sqrtf(-2.0f * kLn2 * __builtin_amdgcn_logf(u01_open(u[0])));
+            const float rev = u01_open(u[1]);
+            const float sn = __builtin_amdgcn_sinf(rev), cs = __builtin_amdgcn_cosf(rev);
+            if (!SPH) {  // model.py:387-392
+                xo0 = bo[0] + rad * cs * fexp(bo[2]);
+                xo1 = bo[1] + rad * sn * fexp(bo[3]);
+            } else {     // model.py:298-307
+                xo0 = bo[0] + rad * cs * (fexp(bo[1]) + 1e-3f);
+                xo1 = von_mises_sample32(bo[2], kappa, k0, k1, (unsigned)ctr, (unsigned)(ctr >> 32), lane);
+            }
+            xs = h ? xo1 : xo0;
+        }
+        auto base_pdf = [&](float a0, float a1) -> float {
+            const float log2pi = 1.8378770664093453f;
+            if (!SPH) {  // model.py:393-398
+                const float e0 = (a0 - bo[0]) * fexp(-bo[2]);
+                const float e1 = (a1 - bo[1]) * fexp(-bo[3]);
+                return fexp(-log2pi - (bo[2] + bo[3]) - 0.5f * (e0 * e0 + e1 * e1));
+            } else {     // model.py:308-317
+                const float e = (a0 - bo[0]) * __builtin_amdgcn_rcpf(fexp(bo[1]) + 1e-3f);
+                const float loggau = -0.5f * log2pi - bo[1] - 0.5f * e * e;
+                float sd_, cd_;
+                sincos_enc(a1 - bo[2], sd_, cd_);
+                const float logvon = kappa * cd_ - log2pi - log_i0(kappa);
+                return fexp(loggau + logvon);
+            }
+        };
+        float p0 = 1.0f;
+        if (op == OP_SAMPLE) p0 = base_pdf(xo0, xo1);
+
+        // ---------------- T explicit Euler steps ---------------------------------------------------
+        float acc = 1.0f;
+        for (int t = 0; t < p.T; ++t) {
+            asm volatile("s_nop 0");   // keeps the weight-fragment loads inside the loop (bsdfd.hip, the same statement)
+            float alpha;
+            if (t_pow2) {
+                const float tf = (float)t * invT;
+                alpha = reverse ? 1.0f - tf : tf;
+            } else {
+                const double tf = (double)t * invT_d;
+                alpha = (float)(reverse ? 1.0 - tf : tf);
+            }
+            // ---- layer 1: one fp16 MFMA, B slots [v_hi, v_lo, v_hi, w_hi, w_lo, w_hi, 0, 0] ----
+            float vin = xs, win = alpha, sp = 0.f, cp = 0.f;
+            if (SPH) {
+                sincos_enc(xs, sp, cp);   // (meaningful in the upper half, whose xs is phi)
+                vin = h ? sp : xs;
+                win = h ? cp : alpha;
+            }
+            const float vh = hi_part(vin), wh = hi_part(win);
+            const _Float16 vh16 = (_Float16)vh, vl16 = (_Float16)(vin - vh), wh16 = (_Float16)wh, wl16 = (_Float16)(win - wh);
+            const f16x2 zero2 = {(_Float16)0.0f, (_Float16)0.0f};
+            Frag b1;
+            b1.p[0] = (f16x2){vh16, vl16}; b1.p[1] = (f16x2){vh16, wh16}; b1.p[2] = (f16x2){wl16, wh16}; b1.p[3] = zero2;
+            const f16x8 a1 = *(reinterpret_cast<const f16x8*>(smem + LY::A1) + lane);
+            f32x16 z = mfma32(a1, b1.v, cacc);
+
+            float hv[16], gv[16];
+            Frag bh[2], bl[2], gh[2], gl[2];
+            f32x16 U0, U1;
+            float gm[16];   // silu' of the middle layer: the fp32 factor of the bilinear form
+            if (!SPH) {
+                // ---- MIM, disk 25-32-32-32-2: U_i = F_i g1, R_j = G_j g3, J_ji = sum_k R_j[k] g2[k] U_i[k] (bsdfd.hip, block MIM)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) silu_grad_scaled(z[v], hv[v], gv[v]);
+                split16(hv, bh, bl);
+                split16(gv, gh, gl);
+                {
+                    const Mat32 w2 = load_mat(smem, LY::WH, lane);
+                    z = mfma32(w2.h0, bh[0].v, zero16); z = mfma32(w2.h1, bh[1].v, z);
+                    z = mfma32(w2.h0, bl[0].v, z); z = mfma32(w2.h1, bl[1].v, z);
+                    z = mfma32(w2.l0, bh[0].v, z); z = mfma32(w2.l1, bh[1].v, z);
+                    const Mat32 f0 = load_mat(smem, LY::WF, lane), f1 = load_mat(smem, LY::WF + 4 * FR32, lane);
+                    U0 = mfma32(f0.h0, gh[0].v, zero16); U1 = mfma32(f1.h0, gh[0].v, zero16);
+                    U0 = mfma32(f0.h1, gh[1].v, U0); U1 = mfma32(f1.h1, gh[1].v, U1);
+                    U0 = mfma32(f0.h0, gl[0].v, U0); U1 = mfma32(f1.h0, gl[0].v, U1);
+                    U0 = mfma32(f0.h1, gl[1].v, U0); U1 = mfma32(f1.h1, gl[1].v, U1);
+                    U0 = mfma32(f0.l0, gh[0].v, U0); U1 = mfma32(f1.l0, gh[0].v, U1);
+                    U0 = mfma32(f0.l1, gh[1].v, U0); U1 = mfma32(f1.l1, gh[1].v, U1);
+                }
+                // hidden layer 2 (its silu' stays in fp32)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) silu_grad_scaled(z[v], hv[v], gm[v]);
+                split16(hv, bh, bl);
+                {
+                    const Mat32 w3 = load_mat(smem, LY::WH + 4 * FR32, lane);
+                    z = mfma32(w3.h0, bh[0].v, zero16); z = mfma32(w3.h1, bh[1].v, z);
+                    z = mfma32(w3.h0, bl[0].v, z); z = mfma32(w3.h1, bl[1].v, z);
+                    z = mfma32(w3.l0, bh[0].v, z); z = mfma32(w3.l1, bh[1].v, z);
+                }
+            } else {
+                // ---- MIMS, spherical 26-32-32-32-32-2: two forward-mode tangent layers, then the output fold (bsdfd.hip, block MIMS)
+                f32x16 zt0, zt1;
+                {
+                    // d(input)/dphi = (0, cos phi, -sin phi, 0): the upper lanes' slots [c_hi, c_lo, c_hi, -s_hi, -s_lo, -s_hi] against
+                    // the same A fragment; the lower lanes (theta, alpha) contribute nothing
+                    Frag bt;
+                    bt.p[0] = h ? (f16x2){wh16, wl16} : zero2;
+                    bt.p[1] = h ? (f16x2){wh16, -vh16} : zero2;
+                    bt.p[2] = h ? (f16x2){-vl16, -vh16} : zero2;
+                    bt.p[3] = zero2;
+                    zt1 = mfma32(a1, bt.v, zero16);
+                    const f32x4* Lwt0 = reinterpret_cast<const f32x4*>(smem + LY::WT0) + lane * 4;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 t4 = Lwt0[k];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) zt0[4 * k + r] = t4[r];
+                    }
+                }
+#pragma unroll
+                for (int layer = 0; layer < 2; ++layer) {
+                    float t0v[16], t1v[16];
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        silu_grad_scaled(z[v], hv[v], gv[v]);
+                        t0v[v] = zt0[v] * gv[v];
+                        t1v[v] = zt1[v] * gv[v];
+                    }
+                    Frag t0h[2], t0l[2], t1h[2], t1l[2];
+                    split16(hv, bh, bl);
+                    split16(t0v, t0h, t0l);
+                    split16(t1v, t1h, t1l);
+                    const Mat32 w = load_mat(smem, LY::WH + layer * 4 * FR32, lane);
+                    z = mfma32(w.h0, bh[0].v, zero16); z = mfma32(w.h1, bh[1].v, z);
+                    z = mfma32(w.h0, bl[0].v, z); z = mfma32(w.h1, bl[1].v, z);
+                    z = mfma32(w.l0, bh[0].v, z); z = mfma32(w.l1, bh[1].v, z);
+                    zt0 = mfma32(w.h0, t0h[0].v, zero16); zt1 = mfma32(w.h0, t1h[0].v, zero16);
+                    zt0 = mfma32(w.h1, t0h[1].v, zt0); zt1 = mfma32(w.h1, t1h[1].v, zt1);
+                    zt0 = mfma32(w.h0, t0l[0].v, zt0); zt1 = mfma32(w.h0, t1l[0].v, zt1);
+                    zt0 = mfma32(w.h1, t0l[1].v, zt0); zt1 = mfma32(w.h1, t1l[1].v, zt1);
+                    zt0 = mfma32(w.l0, t0h[0].v, zt0); zt1 = mfma32(w.l0, t1h[0].v, zt1);
+                    zt0 = mfma32(w.l1, t0h[1].v, zt0); zt1 = mfma32(w.l1, t1h[1].v, zt1);
+                }
+                U0 = zt0; U1 = zt1;
+                // hidden layer 3 (its silu' stays in fp32)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) silu_grad_scaled(z[v], hv[v], gm[v]);
+                split16(hv, bh, bl);
+                {
+                    const Mat32 w4 = load_mat(smem, LY::WH + 2 * 4 * FR32, lane);
+                    z = mfma32(w4.h0, bh[0].v, zero16); z = mfma32(w4.h1, bh[1].v, z);
+                    z = mfma32(w4.h0, bl[0].v, z); z = mfma32(w4.h1, bl[1].v, z);
+                    z = mfma32(w4.l0, bh[0].v, z); z = mfma32(w4.l1, bh[1].v, z);
+                }
+            }
+            // ---- last hidden layer -> R0, R1 (MFMA), v (fp32 VALU dot over the lane's 16 units + one swap) ----
+#pragma unroll
+            for (int v = 0; v < 16; ++v) silu_grad_scaled(z[v], hv[v], gv[v]);
+            split16(gv, gh, gl);
+            f32x16 R0, R1;
+            {
+                const Mat32 g0 = load_mat(smem, LY::WG, lane), g1 = load_mat(smem, LY::WG + 4 * FR32, lane);
+                R0 = mfma32(g0.h0, gh[0].v, zero16); R1 = mfma32(g1.h0, gh[0].v, zero16);
+                R0 = mfma32(g0.h1, gh[1].v, R0); R1 = mfma32(g1.h1, gh[1].v, R1);
+                R0 = mfma32(g0.h0, gl[0].v, R0); R1 = mfma32(g1.h0, gl[0].v, R1);
+                R0 = mfma32(g0.h1, gl[1].v, R0); R1 = mfma32(g1.h1, gl[1].v, R1);
+                R0 = mfma32(g0.l0, gh[0].v, R0); R1 = mfma32(g1.l0, gh[0].v, R1);
+                R0 = mfma32(g0.l1, gh[1].v, R0); R1 = mfma32(g1.l1, gh[1].v, R1);
+            }
+            {
+                const f32x4* Lwo = reinterpret_cast<const f32x4*>(smem + LY::WOUT + h * 128);
+                f32x2 pv = {0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const f32x4 w = Lwo[k];
+                    pv = __builtin_elementwise_fma((f32x2){hv[2 * k], hv[2 * k]}, (f32x2){w[0], w[1]}, pv);
+                    pv = __builtin_elementwise_fma((f32x2){hv[2 * k + 1], hv[2 * k + 1]}, (f32x2){w[2], w[3]}, pv);
+                }
+                float pv0 = pv[0], pv1 = pv[1];
+                swap32(pv0, pv1);            // lower: v0 over the lane pair | upper: v1
+                xs = fmaf(cstep, pv0 + pv1, xs);
+            }
+            // ---- J_ji = sum_k R_j[k] gm[k] U_i[k] over the lane's 16 units, then over the query's 2 lanes; det(I + c J) ----
+            {
+                f32x2 ja2 = {0.f, 0.f}, jb2 = ja2, jc2 = ja2, jd2 = ja2;  // J00, J11, J01, J10
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const f32x2 gg2 = {gm[2 * k], gm[2 * k + 1]};
+                    const f32x2 r0 = {R0[2 * k], R0[2 * k + 1]}, r1 = {R1[2 * k], R1[2 * k + 1]};
+                    const f32x2 u0 = gg2 * (f32x2){U0[2 * k], U0[2 * k + 1]};
+                    const f32x2 u1 = gg2 * (f32x2){U1[2 * k], U1[2 * k + 1]};
+                    ja2 = __builtin_elementwise_fma(r0, u0, ja2);
+                    jc2 = __builtin_elementwise_fma(r0, u1, jc2);
+                    jd2 = __builtin_elementwise_fma(r1, u0, jd2);
+                    jb2 = __builtin_elementwise_fma(r1, u1, jb2);
+                }
+                float ja = ja2[0] + ja2[1], jb = jb2[0] + jb2[1], jc = jc2[0] + jc2[1], jd = jd2[0] + jd2[1];
+                swap32(ja, jb);
+                const float sab = ja + jb;    // lower: J00 | upper: J11
+                swap32(jc, jd);
+                const float scd = jc + jd;    // lower: J01 | upper: J10
+                float w = fmaf(cstep, sab, 1.0f), o = cstep * scd;
+                swap32(w, o);                 // lower: (w00, w11) | upper: (o01, o10)
+                float pr = w * o, pr2 = pr;
+                swap32(pr, pr2);              // lower: pr = w00 w11, pr2 = o01 o10
+                const float det = pr - pr2;   // valid in the lower half (the lanes that write the results)
+                if (reverse) acc *= det; else acc *= __builtin_amdgcn_rcpf(det);
+            }
+        }
+
+        // ---------------- epilogue: density, warp, guards, store ------------------------------------
+        float x0, x1;
+        both32(xs, x0, x1);
+        float pdf = 0.0f;
+        if (op == OP_SAMPLE) pdf = p0 * acc;
+        else if (op == OP_PDF) pdf = base_pdf(x0, x1) * acc;
+
+        const bool writer = valid && h == 0;
+        if (p.io == IO_OPERATOR) {
+            if (writer) {
+                if (op != OP_PDF) reinterpret_cast<float2*>(p.out_x)[qi] = make_float2(x0, x1);
+                if (op != OP_SAMPLES_ONLY) out_pdf[qi] = pdf;
+            }
+        } else if (op == OP_SAMPLE) {
+            float ox, oy, oz, pdf_sa;
+            if (!SPH) {  // rendering/brdf_measured_disk.py:69-82
+                const float r2 = x0 * x0 + x1 * x1;
+                const bool ok = r2 < 0.995f;
+                ox = ok ? x0 : 0.0f; oy = ok ? x1 : 0.0f;
+                oz = sqrtf(fmaxf(1.0f - (ox * ox + oy * oy), 0.0f));
+                pdf_sa = (ok ? pdf : 0.0f) * oz;
+            } else {  // rendering/brdf_measured_spherical.py:79-91, bsdf_myresult.py:69-84
+                float st, ct, sp, cp;
+                sincos_enc(x0, st, ct);
+                sincos_enc(x1, sp, cp);
+                if (!(st > 0.00005f)) pdf = 0.0f;
+                if (p.io == IO_PLUGIN && !(ct > 0.0f)) pdf = 0.0f;
+                ox = cp * st; oy = sp * st; oz = ct;
+                const float inv = fminf(fmaxf(1.0f / sqrtf(ox * ox + oy * oy), 1.0f), 3.402823466e+38f);
+                pdf_sa = pdf * inv;
+            }
+            if (writer) {
+                p.out_x[qi * 3 + 0] = ox; p.out_x[qi * 3 + 1] = oy; p.out_x[qi * 3 + 2] = oz;
+                out_pdf[qi] = pdf_sa;
+            }
+        } else {
+            float pdf_sa;
+            if (!SPH) {  // rendering/brdf_measured_disk.py:112-124
+                pdf_sa = (wi_z > 0.0f && wo_z > 0.0f) ? pdf * wo_z : 0.0f;
+            } else {
+                const float inv = fminf(fmaxf(1.0f / wo_sin, 1.0f), 3.402823466e+38f);
+                if (p.io == IO_PLUGIN) {  // rendering/brdf_measured_spherical.py:122-137
+                    if (wo_pole) pdf = 0.0f;
+                    pdf_sa = (wi_z > 0.0f && wo_z > 0.0f) ? pdf * inv : 0.0f;
+                } else {                  // rendering/bsdf_myresult.py:115-133
+                    pdf_sa = pdf * inv;
+                }
+            }
+            if (writer) out_pdf[qi] = pdf_sa;
+        }
+        }
+        if (FUSED && ++ph < nphase) goto next_phase;
+    }
+    if (p.clk) {
+        const unsigned long long dc = (unsigned long long)__builtin_readcyclecounter() - clk_c0;
+        const unsigned long long dr = (unsigned long long)__builtin_amdgcn_s_memrealtime() - clk_r0;
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long* slot = p.clk + 8 * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (CLK_SLOTS - 1));
+            atomicAdd(slot, dc);
+            atomicAdd(slot + 1, dr);
+        }
+    }
+}
+
+inline uint16_t f16_bits(float x) {
+    const _Float16 hh = (_Float16)x;
+    uint16_t b;
+    std::memcpy(&b, &hh, 2);
+    return b;
+}
+inline float f16_rnd(float x) { return (float)(_Float16)x; }
+
+template <int DOMAIN>
+std::vector<char> build_image32_t(const bsdfd_desc& d) {
+    using LY = L32<DOMAIN>;
+    constexpr bool SPH = LY::SPH;
+    constexpr int NH = LY::NH, W = 32;
+    const int SD = SPH ? 3 : 2, IN = SD + 1 + 2 + 4 * PE_BANDS, BIN = 2 + 4 * BASE_PE_BANDS;
+    // scaled pre-activation convention (flow_dev.h: silu_grad_scaled): first layer x -log2(e), output layer x -ln 2
+    std::vector<float> w_in((size_t)W * IN), w_out((size_t)2 * W);
+    for (size_t i = 0; i < w_in.size(); ++i) w_in[i] = (float)((double)d.w_in[i] * -1.4426950408889634);
+    for (size_t i = 0; i < w_out.size(); ++i) w_out[i] = (float)((double)d.w_out[i] * -0.6931471805599453);
+    std::vector<char> img(LY::TOTAL, 0);
+    auto F = [&](int o) { return reinterpret_cast<float*>(img.data() + o); };
+    auto H = [&](int o) { return reinterpret_cast<uint16_t*>(img.data() + o); };
+    // one matrix = 4 fragments (hi c0, hi c1, lo c0, lo c1); val(row, k) in double
+    auto put_matrix = [&](int off, auto&& val) {
+        for (int c = 0; c < 2; ++c)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int hh = l >> 5, row = l & 31, k = unit32(8 * c + j, hh);
+                    const double v = val(row, k);
+                    const float hi = f16_rnd((float)v);
+                    H(off)[(size_t)(c * 64 + l) * 8 + j] = f16_bits((float)v);
+                    H(off)[(size_t)((2 + c) * 64 + l) * 8 + j] = f16_bits((float)(v - (double)hi));
+                }
+    };
+    // layer-1 state fragment: slots [Wv_hi, Wv_hi, Wv_lo, Ww_hi, Ww_hi, Ww_lo, 0, 0]
+    for (int l = 0; l < 64; ++l) {
+        const int hh = l >> 5, row = l & 31;
+        float wv, ww;
+        if (!SPH) {   // columns [x0, x1, alpha]
+            wv = w_in[(size_t)row * IN + hh];
+            ww = hh == 0 ? w_in[(size_t)row * IN + 2] : 0.0f;
+        } else {      // columns [theta, sin phi, cos phi, alpha]
+            wv = w_in[(size_t)row * IN + (hh == 0 ? 0 : 1)];
+            ww = w_in[(size_t)row * IN + (hh == 0 ? 3 : 2)];
+        }
+        const float s[8] = {f16_rnd(wv), f16_rnd(wv), wv - f16_rnd(wv), f16_rnd(ww), f16_rnd(ww), ww - f16_rnd(ww), 0.f, 0.f};
+        for (int j = 0; j < 8; ++j) H(LY::A1)[(size_t)l * 8 + j] = f16_bits(s[j]);
+    }
+    if (SPH)
+        for (int l = 0; l < 64; ++l)
+            for (int v = 0; v < 16; ++v) F(LY::WT0)[(size_t)l * 16 + v] = w_in[(size_t)unit32(v, l >> 5) * IN + 0];
+    // conditioning term: encoded value index ei (= 2 band + fn; 10 = the raw coordinate) of dimension hh
+    auto pe_col = [&](int ei, int hh) { return ei < 10 ? SD + 1 + 2 + 4 * (ei >> 1) + 2 * (ei & 1) + hh : SD + 1 + hh; };
+    if (!SPH) {
+        for (int c = 0; c < 2; ++c)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int hh = l >> 5, row = l & 31, ei = 8 * c + j;
+                    const float w = ei < 11 ? w_in[(size_t)row * IN + pe_col(ei, hh)] : 0.0f;
+                    H(LY::WC)[(size_t)(c * 64 + l) * 8 + j] = f16_bits(w);
+                    H(LY::WC)[(size_t)((2 + c) * 64 + l) * 8 + j] = f16_bits(w - f16_rnd(w));
+                }
+    } else {
+        for (int j = 0; j < 11; ++j)
+            for (int l = 0; l < 64; ++l) F(LY::WC)[(size_t)j * 64 + l] = w_in[(size_t)(l & 31) * IN + pe_col(j, l >> 5)];
+    }
+    for (int layer = 0; layer < NH - 1; ++layer)
+        put_matrix(LY::WH + layer * 4 * FR32, [&](int row, int k) { return (double)d.w_hidden[((size_t)layer * W + row) * W + k]; });
+    if (!SPH)
+        for (int i = 0; i < 2; ++i)   // F_i = W2 diag(W1[:, i]) (scaled layer-1 column)
+            put_matrix(LY::WF + i * 4 * FR32,
+                       [&](int row, int k) { return (double)d.w_hidden[(size_t)row * W + k] * (double)w_in[(size_t)k * IN + i]; });
+    for (int i = 0; i < 2; ++i)       // G_i[unit][k] = W_NH[k][unit] Wout[i][k] (Wout scaled by -ln 2)
+        put_matrix(LY::WG + i * 4 * FR32, [&](int row, int k) {
+            return (double)d.w_hidden[((size_t)(NH - 2) * W + k) * W + row] * (double)w_out[(size_t)i * W + k];
+        });
+    for (int hh = 0; hh < 2; ++hh)
+        for (int v = 0; v < 16; ++v) {
+            F(LY::WOUT)[hh * 32 + 2 * v] = w_out[unit32(v, hh)];
+            F(LY::WOUT)[hh * 32 + 2 * v + 1] = w_out[W + unit32(v, hh)];
+        }
+    // base net: inputs [y0, y1, PE_3]; PE entry (band b, fn f, dim dd) at column 2 + 4 b + 2 f + dd
+    for (int j = 0; j < 7; ++j)
+        for (int l = 0; l < 64; ++l) {
+            const int hh = l >> 5, row = l & 31;
+            const int col = j == 0 ? hh : 2 + 4 * ((j - 1) >> 1) + 2 * ((j - 1) & 1) + hh;
+            F(LY::BW1)[(size_t)j * 64 + l] = row < BASE_HIDDEN ? d.base_w1[(size_t)row * BIN + col] : 0.0f;
+        }
+    for (int hh = 0; hh < 2; ++hh)
+        for (int v = 0; v < 8; ++v) {
+            F(LY::BB1)[hh * 8 + v] = d.base_b1[unit32(v, hh)];
+            for (int j = 0; j < 4; ++j) F(LY::BW2)[(hh * 8 + v) * 4 + j] = d.base_w2[(size_t)j * BASE_HIDDEN + unit32(v, hh)];
+        }
+    for (int j = 0; j < 4; ++j) F(LY::BB2)[j] = d.base_b2[j];
+    return img;
+}
+
+}  // namespace
+
+bool bsdfd_tile32_supported(const bsdfd_desc& d, int prec) {
+    if (prec != BSDFD_PREC_SPLIT3 || d.width != 32) return false;
+    return (d.domain == BSDFD_DOMAIN_DISK && d.n_hidden == 3) || (d.domain == BSDFD_DOMAIN_SPHERICAL && d.n_hidden == 4);
+}
+
+std::vector<char> bsdfd_build_image32(const bsdfd_desc& d) {
+    return d.domain == BSDFD_DOMAIN_DISK ? build_image32_t<BSDFD_DOMAIN_DISK>(d) : build_image32_t<BSDFD_DOMAIN_SPHERICAL>(d);
+}
+
+const void* bsdfd_kernel32(int domain, int mode) {
+    if (mode == 1)
+        return domain == BSDFD_DOMAIN_DISK ? reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_DISK, false>)
+                                           : reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_SPHERICAL, false>);
+    return nullptr;
+}

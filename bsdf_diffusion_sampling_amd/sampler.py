@@ -42,9 +42,10 @@ def default_binding() -> str:
 
 class FlowSampler:
     def __init__(self, fw: "W.FlowWeights | str", precision: str = "default", device: Optional[int] = None,
-                 binding: Optional[str] = None):
+                 binding: Optional[str] = None, tile: int = 0):
         """``binding``: 'ctypes' or 'torch' — which host shim the per-call entry points go through (default:
-        ``default_binding()``).  The handle is created through the C ABI either way and is the same object."""
+        ``default_binding()``).  The handle is created through the C ABI either way and is the same object.
+        ``tile``: bsdfd_desc.tile — 0 (library default / $BSDFD_TILE), 16 or 32 queries per wave tile."""
         if not torch.cuda.is_available():
             raise RuntimeError("FlowSampler needs an MI355X (torch.cuda is unavailable); there is no CPU path")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
@@ -57,6 +58,7 @@ class FlowSampler:
         d.domain, d.width, d.n_hidden, d.pe_bands = fw.domain, fw.width, fw.n_hidden, fw.pe_bands
         d.base_hidden, d.base_pe_bands = fw.base_hidden, fw.base_pe_bands
         d.precision = _lib.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
+        d.tile = int(tile)
         keep = []
         for name in ("w_in", "w_hidden", "w_out", "base_w1", "base_b1", "base_w2", "base_b2"):
             a = np.ascontiguousarray(getattr(fw, name), dtype=np.float32)

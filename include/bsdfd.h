@@ -64,7 +64,10 @@ typedef struct bsdfd_desc {
     int32_t base_hidden;    /* hidden width of the base-density net (16)                 */
     int32_t base_pe_bands;  /* positional-encoding bands of the base net (3)             */
     int32_t precision;      /* BSDFD_PREC_*                                              */
-    int32_t reserved;
+    int32_t tile;           /* queries per wave64 tile of the Jacobian kernels: 0 = library default (overridable with
+                             * $BSDFD_TILE), 16 = the 16x16x32-MFMA kernels, 32 = the 32x32x16-MFMA kernels (the reference's two
+                             * plugin nets — disk 32x3, spherical 32x4 — in BSDFD_PREC_SPLIT3; silently 16 for anything else).
+                             * Both tilings implement the same operators to the same tolerance. */
     const float* w_in;      /* [width, state_dim + 1 + 2 + 4*pe_bands], cols [state|alpha|PE(omega_i)] */
     const float* w_hidden;  /* [n_hidden-1, width, width]                                */
     const float* w_out;     /* [2, width]                                                */
