@@ -73,14 +73,18 @@ def euler_loop(body: List[str]):
     return min((span, rng) for n, span, rng in cand if 2 * n >= top)[1]
 
 
+_AGPR_BASE = 100000   # accumulation registers a0.. live in their own index space
+
+
 def _regs(tok: str) -> set:
-    """VGPR indices named by an operand token: v12 -> {12}, v[4:7] -> {4..7}."""
-    m = re.fullmatch(r"v(\d+)", tok)
+    """Vector registers named by an operand token: v12 -> {12}, v[4:7] -> {4..7}; AGPRs a3 / a[0:3] -> {_AGPR_BASE + i}."""
+    m = re.fullmatch(r"([va])(\d+)", tok)
     if m:
-        return {int(m.group(1))}
-    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        return {int(m.group(2)) + (_AGPR_BASE if m.group(1) == "a" else 0)}
+    m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", tok)
     if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        base = _AGPR_BASE if m.group(1) == "a" else 0
+        return set(range(base + int(m.group(2)), base + int(m.group(3)) + 1))
     return set()
 
 
@@ -189,16 +193,32 @@ def check_mfma_hazards_lines(lines: List[str], key: str) -> Tuple[int, List[str]
         need_r, need_w = MFMA_WAIT.get(re.sub(r"_(e32|e64)$", "", op), MFMA_WAIT_DEFAULT)
         dst = _regs(toks[0]) if toks else set()
         if not dst:
+            bad.append(f"`{code}`: destination operand not understood — cannot verify its wait states")
             continue
-        stack, seen = [(i + 1, 0)], {}
+        # walk every path from the MFMA; `cur` = the destination registers that still hold ITS result (an instruction that
+        # rewrites some of them takes those over: its own walk answers for them)
+        stack, seen = [(i + 1, 0, frozenset(dst))], {}
         while stack:
-            j, w = stack.pop()
-            while j < len(ins) and w < max(need_r, need_w):
-                if seen.get(j, 1 << 30) <= w:
+            j, w, cur = stack.pop()
+            while j < len(ins) and w < max(need_r, need_w) and cur:
+                if seen.get((j, cur), 1 << 30) <= w:
                     break
-                seen[j] = w
+                seen[(j, cur)] = w
                 o, t, c = ins[j]
-                if not _is_mfma(o) and t:
+                if _is_mfma(o) and len(t) >= 4:
+                    # a later MFMA: the matrix pipe interlocks an accumulator it takes over UNCHANGED (SrcC == the earlier vDst, the
+                    # back-to-back accumulation these kernels use); a result consumed as SrcA / SrcB, or a partially overlapping
+                    # SrcC, needs the software wait states like any other reader
+                    srcs = set().union(*[_regs(x) for x in t[1:3]])
+                    c_regs = _regs(t[3])
+                    if c_regs != dst or cur != dst:
+                        srcs |= c_regs
+                    if cur & srcs and w < need_r:
+                        bad.append(f"`{c}` reads the destination of `{code}` as a matrix operand after {w} wait states (needs {need_r})")
+                        stack.clear()
+                        break
+                    cur = cur - _regs(t[0])      # (an accumulating MFMA rewrites its SrcC; either way the registers are its own now)
+                elif t:
                     has_dst = o.startswith("v_") and not o.startswith("v_cmp") and not o.startswith("v_readlane") \
                         and not o.startswith("v_readfirstlane")
                     is_load = o.startswith(_LOADS)
@@ -206,19 +226,21 @@ def check_mfma_hazards_lines(lines: List[str], key: str) -> Tuple[int, List[str]
                     reads = set().union(*[_regs(x) for x in (t[1:] if (has_dst or is_load) else t)]) if t else set()
                     if o.startswith("v_writelane") or o.startswith("v_fmac") or o.startswith("v_pk_fmac"):
                         reads |= writes          # read-modify-write destinations
-                    if (dst & reads and w < need_r) or (dst & writes and has_dst and w < need_w):
-                        kind = "reads" if dst & reads else "overwrites"
+                    if o.startswith("v_permlane") and "swap" in o and len(t) > 1:
+                        writes = writes | _regs(t[1])   # a swap reads and writes both operands
+                        reads = reads | writes
+                    if (cur & reads and w < need_r) or (cur & writes and has_dst and w < need_w):
+                        kind = "reads" if cur & reads else "overwrites"
                         bad.append(f"`{c}` {kind} the destination of `{code}` after {w} wait states "
                                    f"(needs {need_r if kind == 'reads' else need_w})")
                         stack.clear()
                         break
-                    if dst <= writes and not (dst & reads):
-                        break                    # fully redefined: later uses see the new value
+                    cur = cur - writes           # redefined registers: later uses see the new value
                 if o == "s_endpgm":
                     break
                 m = re.search(r"(\.LBB\d+_\d+)", c) if o.startswith("s_cbranch") or o == "s_branch" else None
                 if m and m.group(1) in label_at:
-                    stack.append((label_at[m.group(1)], w + 1))
+                    stack.append((label_at[m.group(1)], w + 1, cur))
                     if o == "s_branch":
                         break
                 if o == "s_nop" and t:
@@ -227,6 +249,103 @@ def check_mfma_hazards_lines(lines: List[str], key: str) -> Tuple[int, List[str]
                     w += 1
                 j += 1
     return n_mfma, bad
+
+
+# ---- census: what a build MUST contain (the checks above report "no violations" for a kernel they do not find or cannot parse) ----
+# Instantiation table of csrc/bsdfd.hip::kernel_ptr (mirrored here; tests/test_host_cpu.py holds the two in step): every
+# (domain, width / 16, depths) x precision x {no Jacobian, Jacobian, Jacobian + fused sample/pdf}, precision f32 always with the
+# run-time-depth loop.  Template arguments <DOMAIN, NM, PREC, JAC, NH, FUSED>.
+_PREC_F32, _PREC_SPLIT3, _PREC_F16 = 1, 2, 3
+
+
+def expected_flow_kernels(variant: str = "async") -> Dict[str, Dict[str, int]]:
+    """Mangled-name fragment of every flow kernel the library is built from -> the least number of asynchronous `ds_read_b128`
+    and of their wait statements its assembly must show (0 for the kernels that use none and for the `plain` fallback variant)."""
+    out = {}
+    for dom, shapes in ((0, ((2, (3, 0)), (4, (0,)))), (1, ((2, (4, 0)), (4, (6, 0))))):
+        for nm, depths in shapes:
+            for prec in (_PREC_F32, _PREC_SPLIT3, _PREC_F16):
+                for nh in ((0,) if prec == _PREC_F32 else depths):
+                    for jac, fused in ((0, 0), (1, 0), (1, 1)):
+                        spec = {"async": 0, "waits": 0}
+                        if variant == "async" and jac and nm == 2 and prec != _PREC_F32:
+                            split = prec == _PREC_SPLIT3
+                            if dom == 0 and nh == 3:      # block MIM: 25 (13) fragment reads, 5 (3) waits per step
+                                spec = {"async": 25 if split else 13, "waits": 5 if split else 3}
+                            elif dom == 1 and nh == 4:    # block MIMS: 21 (11) reads, 5 (4) waits
+                                spec = {"async": 21 if split else 11, "waits": 5 if split else 4}
+                        out[f"flow_kernelILi{dom}ELi{nm}ELi{prec}ELb{jac}ELi{nh}ELb{fused}EE"] = spec
+    for dom in (0, 1):                                    # csrc/flow32.hip: <DOMAIN, JAC, FUSED>, compiler-managed LDS reads
+        for jac, fused in ((0, 0), (1, 0), (1, 1)):
+            out[f"flow_kernel32ILi{dom}ELb{jac}ELb{fused}EE"] = {"async": 0, "waits": 0}
+    return out
+
+
+def census_lines(lines: List[str], fragment: str = "flow_kernel") -> Dict[str, Dict[str, int]]:
+    """Per kernel: MFMAs parsed, asynchronous reads and wait statements found (inside inline-asm brackets), and the .amdhsa
+    metadata (an empty dict when the metadata block was not found)."""
+    out = {}
+    for k in kernel_names(lines, fragment):
+        body = kernel_body(lines, k)
+        n_mfma = n_async = n_wait = 0
+        in_asm = False
+        for raw in body:
+            l = raw.strip()
+            if l.startswith(";;#ASMSTART") or l.startswith(";#ASMSTART"):
+                in_asm = True
+                continue
+            if l.startswith(";;#ASMEND") or l.startswith(";#ASMEND"):
+                in_asm = False
+                continue
+            code = l.split(";")[0].strip()
+            if not code:
+                continue
+            op = code.split()[0]
+            if _is_mfma(op):
+                n_mfma += 1
+            if in_asm and op == "ds_read_b128":
+                n_async += 1
+            if in_asm and op.startswith("s_waitcnt") and "lgkmcnt(0)" in code:
+                n_wait += 1
+        out[k] = {"mfma": n_mfma, "async": n_async, "waits": n_wait, "meta": kernel_meta(lines, k)}
+    return out
+
+
+def verify_census(asm_paths: List[str], variant: str = "async", allow_scratch: bool = False, only: str = None) -> List[str]:
+    """Problems that make the other checks of this module meaningless or the build unshippable: an expected flow kernel missing
+    from the assembly (renamed labels, another mangling), an unexpected one, a kernel in which the parser sees no MFMA, fewer
+    asynchronous reads / waits than the source issues (another mnemonic spelling), no metadata, or scratch memory in use.
+    ``only``: restrict the expectation to the kernels whose name fragment starts with it ("flow_kernelI": csrc/bsdfd.hip,
+    "flow_kernel32I": csrc/flow32.hip)."""
+    found = {}
+    for path in asm_paths:
+        found.update(census_lines(open(path).read().splitlines()))
+    expected = {f: v for f, v in expected_flow_kernels(variant).items() if only is None or f.startswith(only)}
+    problems = []
+    by_frag = {}
+    for k, c in found.items():
+        frag = next((f for f in expected if f in k), None)
+        if frag is None and only is not None and only not in k:
+            continue
+        if frag is None:
+            problems.append(f"unexpected flow kernel {k} (not in expected_flow_kernels: update the table with csrc/*.hip)")
+        else:
+            by_frag[frag] = c
+    for frag, spec in expected.items():
+        c = by_frag.get(frag)
+        if c is None:
+            problems.append(f"flow kernel {frag} not found in the assembly")
+            continue
+        if c["mfma"] < 1:
+            problems.append(f"{frag}: no MFMA instruction recognised")
+        if c["async"] < spec["async"] or c["waits"] < spec["waits"]:
+            problems.append(f"{frag}: {c['async']} asynchronous ds_read_b128 / {c['waits']} waits recognised, the source issues "
+                            f"{spec['async']} / {spec['waits']}")
+        if not c["meta"] or "vgpr_count" not in c["meta"]:
+            problems.append(f"{frag}: .amdhsa metadata not found")
+        elif not allow_scratch and c["meta"].get("private_segment_fixed_size", 0) != 0:
+            problems.append(f"{frag}: {c['meta']['private_segment_fixed_size']} B of scratch per lane (spills)")
+    return problems
 
 
 def check_file(path: str, fragment: str = "flow_kernel") -> Dict[str, Tuple[int, List[str]]]:

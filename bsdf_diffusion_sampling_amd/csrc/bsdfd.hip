@@ -133,9 +133,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
     // (the samples-only split3 kernel follows, so that it walks exactly the trajectory of the sampling kernel)
     constexpr bool SPLIT_PRO = PREC == BSDFD_PREC_SPLIT3 && DOMAIN == BSDFD_DOMAIN_DISK;
     const int n_hidden = NH ? NH : p.n_hidden;
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 4;
-    const int q = lane & 15;
+    const int lane_k = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int waves_per_block = blockDim.x >> 6;
 
@@ -159,14 +157,14 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     float win[NM];
 #pragma unroll
-    for (int m = 0; m < NM; ++m) win[m] = Lwin[m * 64 + lane];
+    for (int m = 0; m < NM; ++m) win[m] = Lwin[m * 64 + lane_k];
 
     // layer-1 pre-activations of the constant tangents: d/dx0 (both domains), d/dx1 (disk)
     f32x4 zt0c[NM], zt1c[NM];
 #pragma unroll
     for (int m = 0; m < NM; ++m) {
-        zt0c[m] = mfma4(win[m], g == 0 ? 1.0f : 0.0f, zero4);
-        zt1c[m] = mfma4(win[m], g == 1 ? 1.0f : 0.0f, zero4);
+        zt0c[m] = mfma4(win[m], (lane_k >> 4) == 0 ? 1.0f : 0.0f, zero4);
+        zt1c[m] = mfma4(win[m], (lane_k >> 4) == 1 ? 1.0f : 0.0f, zero4);
     }
 
     const double invT_d = 1.0 / (double)p.T;
@@ -192,9 +190,24 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
         if (chunk_base >= ntiles) break;
         const long long tile = chunk_base + (it & ((1 << cl) - 1)) * waves_per_block + wave;
         if (tile >= ntiles) continue;
-        const long long qi_raw = q_begin + tile * 16 + q;
-        const bool valid = qi_raw < q_end;
-        const long long qi = valid ? qi_raw : q_end - 1;
+        // The fused sample+pdf kernels (REMAT) re-derive the lane number per tile from an opaque copy, and the row of the
+        // lane's query again at the phase switch and in the epilogue: otherwise everything computed from the lane number (LDS
+        // addresses, half-wave selects) is hoisted out of the tile loop and the 64-bit row with every address derived from it is
+        // carried across both Euler loops — the fused spherical split3 kernel spilled 16 VGPRs for that (round 4: 68 B of
+        // scratch per lane).  The single-op kernels keep the plain values (same code as before).
+        constexpr bool REMAT = FUSED;
+        auto opaque = [](int x) -> int { if (REMAT) asm volatile("" : "+v"(x)); return x; };
+        const int lane = opaque(lane_k);
+        const int g = lane >> 4;
+        const int q = lane & 15;
+        const long long tile_q0 = q_begin + tile * 16;
+        auto row_of = [&](int qq, bool& in_range) -> long long {
+            const long long r = tile_q0 + qq;
+            in_range = r < q_end;
+            return in_range ? r : q_end - 1;
+        };
+        bool valid;
+        const long long qi = row_of(q, valid);
 
         // ---------------- inputs: condition (y0,y1) and, for pdf, the outgoing point -------------
         float y0 = 0.f, y1 = 0.f, wi_z = 1.0f;
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
         // plugin io: the direction whose pdf is asked -> start point of the reverse flow.  Disk: its xy; spherical: the arguments of
         // its two angles (evaluated below, one atan2f per lane, together with those of wi where both are needed)
         SphArgs ao = {};
-        auto load_dir = [&](const float* dir) {
+        auto load_dir = [&](const float* dir, long long qi) {
             const float ox = dir[qi * 3 + 0], oy = dir[qi * 3 + 1], oz = dir[qi * 3 + 2];
             wo_z = oz;
             wo_sin = sqrtf(ox * ox + oy * oy);  // Mitsuba Frame3f::sin_theta
@@ -238,7 +251,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
                 y0 = wx; y1 = wy;  // rendering/brdf_measured_disk.py:66-67
             }
             const bool need_o = !FUSED && p.op == OP_PDF;
-            if (need_o) load_dir(p.in_b);  // (the fused kernel loads wl at its phase switch: 4 registers less across phase 1)
+            if (need_o) load_dir(p.in_b, qi);  // (the fused kernel loads wl at its phase switch: 4 registers less across phase 1)
             if (DOMAIN == BSDFD_DOMAIN_SPHERICAL) {  // cart_to_spher, rendering/brdf_measured_spherical.py:35-39 (wave-uniform branches)
                 if (!have_ctx && need_o) {           // pdf(): four angles, one per lane of the query
                     const SphArgs ai = spher_args(wx, wy, wz);
@@ -374,7 +387,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
         float* const out_pdf = (FUSED && ph) ? p.out_pdf2 : p.out_pdf;
         // ---------------- initial state ------------------------------------------------------------
         if (FUSED && ph) {
-            load_dir(p.in_c);
+            bool v2;
+            load_dir(p.in_c, REMAT ? row_of(opaque(q), v2) : qi);
             if (DOMAIN == BSDFD_DOMAIN_SPHERICAL) angles_of(ao, xs0, xs1);
         }
         float x0 = (FUSED && !ph) ? xi0 : xs0, x1 = (FUSED && !ph) ? xi1 : xs1;
@@ -1086,11 +1100,13 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
         if (op == OP_SAMPLE) pdf = p0 * acc;
         else if (op == OP_PDF) pdf = base_pdf(x0, x1) * acc;
 
-        const bool writer = valid && g == 0;
+        bool valid_e = valid;
+        const long long qe = REMAT ? row_of(opaque(q), valid_e) : qi;
+        const bool writer = valid_e && g == 0;
         if (p.io == IO_OPERATOR) {
             if (writer) {
-                if (op != OP_PDF) reinterpret_cast<float2*>(p.out_x)[qi] = make_float2(x0, x1);
-                if (op != OP_SAMPLES_ONLY) out_pdf[qi] = pdf;
+                if (op != OP_PDF) reinterpret_cast<float2*>(p.out_x)[qe] = make_float2(x0, x1);
+                if (op != OP_SAMPLES_ONLY) out_pdf[qe] = pdf;
             }
         } else if (op == OP_SAMPLE) {
             float ox, oy, oz, pdf_sa;
@@ -1111,8 +1127,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
                 pdf_sa = pdf * inv;
             }
             if (writer) {
-                p.out_x[qi * 3 + 0] = ox; p.out_x[qi * 3 + 1] = oy; p.out_x[qi * 3 + 2] = oz;
-                out_pdf[qi] = pdf_sa;
+                p.out_x[qe * 3 + 0] = ox; p.out_x[qe * 3 + 1] = oy; p.out_x[qe * 3 + 2] = oz;
+                out_pdf[qe] = pdf_sa;
             }
         } else {
             float pdf_sa;
@@ -1127,7 +1143,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
                     pdf_sa = pdf * inv;
                 }
             }
-            if (writer) out_pdf[qi] = pdf_sa;
+            if (writer) out_pdf[qe] = pdf_sa;
         }
         }
         if (FUSED && ++ph < nphase) goto next_phase;
@@ -1170,6 +1186,7 @@ struct bsdfd_ctx {
     int tile[3];
     const char* img_of[3];
     int img_bytes[3];
+    int lds_bytes[3];   // dynamic LDS of mode m's kernel (>= img_bytes[m])
     // profiling: a ring of HIP event pairs recorded on the launch stream around every launch.  Everything
     // above this line is immutable after create; the profiling state below is guarded by `prof_mu`, so the
     // handle stays re-entrant across host threads / streams with profiling on (launches that are being timed
@@ -1422,8 +1439,10 @@ const void* kernel_ptr(int domain, int nm, int n_hidden, int prec, int mode) {
     return kernel_ptr_prec<BSDFD_DOMAIN_SPHERICAL, 4, 0>(prec, mode);
 }
 inline int threads_for(int nm) { return nm == 2 ? 256 : 512; }
-// queries per wave tile of the Jacobian kernels when the caller leaves bsdfd_desc.tile at 0 and $BSDFD_TILE is unset
-constexpr int kDefaultTile = 16;
+// queries per wave tile when the caller leaves bsdfd_desc.tile at 0 and $BSDFD_TILE is unset: the 32-query-tile kernels where they
+// exist (round 5, within-run A/B on one box: kernel time 0.925-0.94 of the 16-query kernels' on disk T = 8 / T = 4 and spherical
+// T = 8, sample and pdf, and 0.93 on the fused sample+pdf launches; profiles/r05_ab/)
+constexpr int kDefaultTile = 32;
 // extra dynamic LDS per workgroup: 0 in the product; a tools build (tools/tuning_knobs.h) reads $BSDFD_LDS_PAD to lower the
 // number of resident workgroups per CU (occupancy sweeps of the same binary)
 #ifdef BSDFD_TOOLS_LDS_PAD
@@ -1578,7 +1597,7 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
             HIP_TRY(hipEventRecord(h->ev0[slot], s));
         }
     }
-    hipError_t e = hipLaunchKernel(h->kfun[mode], grid, block, args, (size_t)h->img_bytes[mode] + lds_pad(), s);
+    hipError_t e = hipLaunchKernel(h->kfun[mode], grid, block, args, (size_t)h->lds_bytes[mode] + lds_pad(), s);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) return fail(BSDFD_EHIP, std::string("kernel launch: ") + hipGetErrorString(e));
     if (slot >= 0) {
@@ -1598,8 +1617,8 @@ int run_multi(const bsdfd_handle* hs, int n, const int64_t* seg_end, int op, int
     for (int i = 0; i < n; ++i) {
         if (!hs[i]) return fail(BSDFD_EINVAL, "null handle in the table");
         if (hs[i]->domain != hs[0]->domain || hs[i]->width != hs[0]->width || hs[i]->n_hidden != hs[0]->n_hidden ||
-            hs[i]->precision != hs[0]->precision || hs[i]->device != hs[0]->device || hs[i]->tile[1] != hs[0]->tile[1] ||
-            hs[i]->tile[2] != hs[0]->tile[2])
+            hs[i]->precision != hs[0]->precision || hs[i]->device != hs[0]->device || hs[i]->tile[0] != hs[0]->tile[0] ||
+            hs[i]->tile[1] != hs[0]->tile[1] || hs[i]->tile[2] != hs[0]->tile[2])
             return fail(BSDFD_EINVAL, "handles of one multi-material launch must share domain, width, depth, "
                                       "precision, tile and device");
         if (seg_end[i] < (i ? seg_end[i - 1] : 0)) return fail(BSDFD_EINVAL, "segment ends must be non-decreasing");
@@ -1680,13 +1699,16 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
         want_tile = ev ? std::atoi(ev) : kDefaultTile;
     }
     const bool t32 = want_tile == 32 && bsdfd_tile32_supported(*d, prec);
-    for (int m = 0; m < 3; ++m) { h->tile[m] = 16; h->img_of[m] = h->d_img; h->img_bytes[m] = h->L.total; }
+    for (int m = 0; m < 3; ++m) { h->tile[m] = 16; h->img_of[m] = h->d_img; h->img_bytes[m] = h->lds_bytes[m] = h->L.total; }
     if (t32 && e == hipSuccess) {
         const std::vector<char> img32 = bsdfd_build_image32(*d);
         e = hipMalloc(reinterpret_cast<void**>(&h->d_img32), img32.size());
         if (e == hipSuccess) e = hipMemcpy(h->d_img32, img32.data(), img32.size(), hipMemcpyHostToDevice);
-        for (int m = 1; m < 3; ++m)
-            if (bsdfd_kernel32(h->domain, m)) { h->tile[m] = 32; h->img_of[m] = h->d_img32; h->img_bytes[m] = (int)img32.size(); }
+        for (int m = 0; m < 3; ++m)
+            if (bsdfd_kernel32(h->domain, m)) {
+                h->tile[m] = 32; h->img_of[m] = h->d_img32; h->img_bytes[m] = (int)img32.size();
+                h->lds_bytes[m] = bsdfd_kernel32_lds_bytes(h->domain, m);
+            }
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_clk), (size_t)CLK_SLOTS * 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(h->d_clk, 0, (size_t)CLK_SLOTS * 8 * sizeof(unsigned long long));
@@ -1697,10 +1719,10 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     for (int jac = 0; jac < 3 && e == hipSuccess; ++jac) {
         h->kfun[jac] = h->tile[jac] == 32 ? bsdfd_kernel32(h->domain, jac) : kernel_ptr(h->domain, h->width / 16, h->n_hidden, prec, jac);
         // dynamic LDS above the default cap needs the attribute (per function and device)
-        e = hipFuncSetAttribute(h->kfun[jac], hipFuncAttributeMaxDynamicSharedMemorySize, h->img_bytes[jac] + (int)lds_pad());
+        e = hipFuncSetAttribute(h->kfun[jac], hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes[jac] + (int)lds_pad());
         int nb = 0;
         if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h->kfun[jac], threads_for(h->width / 16), (size_t)h->img_bytes[jac] + lds_pad());
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h->kfun[jac], threads_for(h->width / 16), (size_t)h->lds_bytes[jac] + lds_pad());
         h->per_cu[jac] = nb;
     }
     if (e != hipSuccess) {
@@ -1776,6 +1798,12 @@ int bsdfd_get_info(bsdfd_handle h, int32_t* domain, int32_t* width, int32_t* n_h
     if (width) *width = h->width;
     if (n_hidden) *n_hidden = h->n_hidden;
     if (precision) *precision = h->precision;
+    return BSDFD_OK;
+}
+
+int bsdfd_get_tile(bsdfd_handle h, int32_t* tile) {
+    if (!h || !tile) return fail(BSDFD_EINVAL, "null argument");
+    *tile = h->tile[1];
     return BSDFD_OK;
 }
 
@@ -1974,6 +2002,11 @@ float bsdfd_last_kernel_ms(bsdfd_handle h) {
 }
 
 const char* bsdfd_last_error(void) { return g_err.c_str(); }
-const char* bsdfd_version(void) { return "bsdfd 0.4 (gfx950; " BSDFD_LDS_VARIANT ")"; }
+#ifdef BSDFD_UNVERIFIED_BUILD
+#define BSDFD_VERIFIED_TAG "; UNVERIFIED BUILD: shipped with BSDFD_ALLOW_UNVERIFIED_BUILD=1 although the assembly checks failed"
+#else
+#define BSDFD_VERIFIED_TAG ""
+#endif
+const char* bsdfd_version(void) { return "bsdfd 0.5 (gfx950; " BSDFD_LDS_VARIANT BSDFD_VERIFIED_TAG ")"; }
 
 }  // extern "C"

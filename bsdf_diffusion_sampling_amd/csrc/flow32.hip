@@ -43,6 +43,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int FR32 = 64 * 16;  // bytes of one A fragment (32 rows x 16 K-values of fp16)
 
+// build knobs of the A/B runs (tools/ab_build32.sh); the defaults are the product
+#ifndef BSDFD_T32_WAVES
+#define BSDFD_T32_WAVES 3        // waves per SIMD the register allocator is asked to make room for (168 VGPRs)
+#endif
+#ifndef BSDFD_T32_CACC_LDS
+#define BSDFD_T32_CACC_LDS 2     // the per-query conditioning term in a per-wave LDS slab instead of 16 VGPRs: 0 never, 1 always,
+#endif                           // 2 = the spherical and the fused kernels (they spill at 3 waves/SIMD otherwise; the disk single-op kernel fits)
+#ifndef BSDFD_T32_FUSED_SPH_WAVES
+#define BSDFD_T32_FUSED_SPH_WAVES 2   // the fused spherical sample+pdf kernel keeps more state across its two Euler loops
+#endif
+template <int DOMAIN, bool FUSED>
+struct CaccLds {
+    static constexpr bool on = BSDFD_T32_CACC_LDS == 1 || (BSDFD_T32_CACC_LDS == 2 && (FUSED || DOMAIN == BSDFD_DOMAIN_SPHERICAL));
+    static constexpr int slab = on ? 64 * 64 : 0;   // bytes per wave
+};
+
 // byte offsets into the weight image — compile-time constants per domain (the host's build_image32 uses the same struct)
 template <int DOMAIN>
 struct L32 {
@@ -94,7 +110,17 @@ __device__ __forceinline__ void split16(const float (&x)[16], Frag (&hi)[2], Fra
         }
 }
 
-// acc (+)= (W_hi + W_lo) (x_hi + x_lo) without the lo lo term; the matrix' 4 fragments (hi c0, hi c1, lo c0, lo c1) at `m`
+// a layer's 16 sigmoids: hs = zs sigma, g = silu' (flow_dev.h: silu_grad_scaled); WITH_G = false: hs alone (no Jacobian)
+template <bool WITH_G>
+__device__ __forceinline__ void act16(const f32x16& z, float (&hs)[16], float (&g)[16]) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        if (WITH_G) silu_grad_scaled(z[v], hs[v], g[v]);
+        else hs[v] = z[v] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[v]));
+    }
+}
+
+// one 32 x 32 matrix = 4 fragments (hi chunk 0, hi chunk 1, lo chunk 0, lo chunk 1)
 struct Mat32 {
     f16x8 h0, h1, l0, l1;
 };
@@ -103,6 +129,27 @@ __device__ __forceinline__ Mat32 load_mat(const char* smem, int off, int lane) {
     Mat32 r;
     r.h0 = m[0]; r.h1 = m[64]; r.l0 = m[128]; r.l1 = m[192];
     return r;
+}
+// (W_hi + W_lo) (x_hi + x_lo) without the lo lo term: hi hi + hi lo + lo hi in ONE fp32 accumulator, 6 MFMAs
+__device__ __forceinline__ f32x16 mm6(const Mat32& w, const Frag (&xh)[2], const Frag (&xl)[2]) {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 a = mfma32(w.h0, xh[0].v, zero16);
+    a = mfma32(w.h1, xh[1].v, a);
+    a = mfma32(w.h0, xl[0].v, a);
+    a = mfma32(w.h1, xl[1].v, a);
+    a = mfma32(w.l0, xh[0].v, a);
+    return mfma32(w.l1, xh[1].v, a);
+}
+// two such products issued term by term, alternating accumulators (matrices wa, wb; vectors xa, xb)
+__device__ __forceinline__ void mm6x2(const Mat32& wa, const Frag (&xah)[2], const Frag (&xal)[2], const Mat32& wb, const Frag (&xbh)[2],
+                                      const Frag (&xbl)[2], f32x16& a, f32x16& b) {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    a = mfma32(wa.h0, xah[0].v, zero16); b = mfma32(wb.h0, xbh[0].v, zero16);
+    a = mfma32(wa.h1, xah[1].v, a); b = mfma32(wb.h1, xbh[1].v, b);
+    a = mfma32(wa.h0, xal[0].v, a); b = mfma32(wb.h0, xbl[0].v, b);
+    a = mfma32(wa.h1, xal[1].v, a); b = mfma32(wb.h1, xbl[1].v, b);
+    a = mfma32(wa.l0, xah[0].v, a); b = mfma32(wb.l0, xbh[0].v, b);
+    a = mfma32(wa.l1, xah[1].v, a); b = mfma32(wb.l1, xbh[1].v, b);
 }
 
 // Best & Fisher rejection sampler, 32-query tiles: the 2 lanes of a query test 4 consecutive proposals of the query's Philox
@@ -153,11 +200,12 @@ __device__ __forceinline__ float von_mises_sample32(float mu, float kappa, unsig
 }
 
 // ---------------------------------------------------------------------------------------------
-// The kernel.  DOMAIN: BSDFD_DOMAIN_*; FUSED: the two-phase OP_SAMPLE_PDF loop (its own instantiation).
+// The kernel.  DOMAIN: BSDFD_DOMAIN_*; JAC: track the Jacobian determinant (false: bsdfd_flow_samples_only — the same trajectory
+// as the sampling kernel, bit for bit); FUSED: the two-phase OP_SAMPLE_PDF loop (its own instantiation).
 // 2 waves per SIMD (256 VGPRs): per lane the step keeps 16-register vectors where the 16-query kernels keep 8.
 // ---------------------------------------------------------------------------------------------
-template <int DOMAIN, bool FUSED>
-__global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
+template <int DOMAIN, bool JAC, bool FUSED>
+__global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? BSDFD_T32_FUSED_SPH_WAVES : BSDFD_T32_WAVES) void flow_kernel32(const KParams p) {
     using LY = L32<DOMAIN>;
     constexpr bool SPH = DOMAIN == BSDFD_DOMAIN_SPHERICAL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,16 +232,22 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63;
-    const int h = lane >> 5;
-    const int n = lane & 31;
+    const int lane0 = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int waves_per_block = blockDim.x >> 6;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    const double invT_d = 1.0 / (double)p.T;
+    // launch-uniform values the VALU computes (there is no scalar fp64 divide) are moved to SGPRs: as VGPRs they would be held
+    // across the whole kernel
+    auto uniform_f = [](float x) -> float { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); };
+    auto uniform_d = [](double x) -> double {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    const double invT_d = uniform_d(1.0 / (double)p.T);
     const bool t_pow2 = (p.T & (p.T - 1)) == 0;
-    const float invT = (float)invT_d;
+    const float invT = uniform_f((float)invT_d);
     const int nphase = FUSED ? 2 : 1;
     const bool reverse1 = (p.op == OP_PDF);
     const float cstep1 = reverse1 ? -invT : invT;
@@ -206,9 +260,25 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
         if (chunk_base >= ntiles) break;
         const long long tile = chunk_base + (it & ((1 << cl) - 1)) * waves_per_block + wave;
         if (tile >= ntiles) continue;
-        const long long qi_raw = q_begin + tile * 32 + n;
-        const bool valid = qi_raw < q_end;
-        const long long qi = valid ? qi_raw : q_end - 1;
+        // row of this lane's query (clamped on the ragged last tile).  The epilogue and the fused kernel's phase switch RECOMPUTE it
+        // from the wave-uniform tile base and an opaque copy of the lane number instead of keeping the 64-bit row — and every
+        // address derived from it — in registers across the Euler loop, where there are none to spare (`opaque` stops the
+        // compiler from sharing the computation with the prologue's)
+        // The lane number is re-derived per tile from an opaque copy: everything computed from it (LDS addresses in five
+        // scalings, the half-wave selects) would otherwise be hoisted out of the tile loop and held in registers for the whole
+        // kernel — the fused spherical instantiation spilled 19 of them at kernel entry.
+        auto opaque = [](int x) -> int { asm volatile("" : "+v"(x)); return x; };
+        const int lane = opaque(lane0);
+        const int h = lane >> 5;
+        const int n = lane & 31;
+        const long long tile_q0 = q_begin + tile * 32;
+        auto row_of = [&](int nn, bool& in_range) -> long long {
+            const long long r = tile_q0 + nn;
+            in_range = r < q_end;
+            return in_range ? r : q_end - 1;
+        };
+        bool valid;
+        const long long qi = row_of(n, valid);
 
         // ---------------- inputs ---------------------------------------------------------------------
         // yh: this lane's coordinate of the condition omega_i (lane h encodes dimension h); xs: this lane's coordinate of the
@@ -219,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
         bool wo_pole = false;
         float xi0 = 0.f, xi1 = 0.f;   // FUSED: injected x0
         const bool have_ctx = !FUSED && p.ctx_in != nullptr;
-        auto load_dir = [&](const float* dir) {   // plugin io: the direction whose pdf is asked -> start point of the reverse flow
+        auto load_dir = [&](const float* dir, long long qi) {   // plugin io: the direction whose pdf is asked -> start point of the reverse flow
             const float ox = dir[qi * 3 + 0], oy = dir[qi * 3 + 1], oz = dir[qi * 3 + 2];
             wo_z = oz;
             wo_sin = sqrtf(ox * ox + oy * oy);  // Mitsuba Frame3f::sin_theta
@@ -248,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
                 const SphArgs ai = spher_args(wx, wy, wz);  // rendering/brdf_measured_spherical.py:35-39
                 yh = atan2f(h ? ai.y : ai.s, h ? ai.x : ai.z);
             }
-            if (!FUSED && p.op == OP_PDF) load_dir(p.in_b);
+            if (!FUSED && p.op == OP_PDF) load_dir(p.in_b, qi);
             if ((FUSED || p.op != OP_PDF) && p.in_b != nullptr) {  // injected base sample
                 const float2 b2 = reinterpret_cast<const float2*>(p.in_b)[qi];
                 if (FUSED) { xi0 = b2.x; xi1 = b2.y; } else { xs = h ? b2.y : b2.x; xo0 = b2.x; xo1 = b2.y; }
@@ -256,6 +326,7 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
         }
 
         f32x16 cacc;
+        f32x4* const cslab = reinterpret_cast<f32x4*>(smem + LY::TOTAL + wave * CaccLds<DOMAIN, FUSED>::slab) + lane;   // [k][lane] f32x4
         f32x4 bo;
         constexpr long long CTX_V4 = 4 * 64 + 32;  // f32x4 per tile: cacc (4 per lane) + bo per query
         const long long ctx_slot = ((q_begin + tile * 32) >> 5) + p.seg_base + sidx;
@@ -273,7 +344,12 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
             // e[2 b + fn] = fn(2^b y_h), fn = sin, cos; e[10] = y_h  (rendering/utils/model.py:26-57)
             float e[11];
 #pragma unroll
-            for (int b = 0; b < PE_BANDS; ++b) sincos_enc(yh * (float)(1 << b), e[2 * b], e[2 * b + 1]);
+            for (int b = 0; b < PE_BANDS; ++b) {
+                // (the fused kernel is plugin io only: there a spherical condition is an atan2f result, |2^b y| <= 16 pi, and the
+                //  general-argument branch of sincos_enc is dead code — which the compiler cannot know and pays registers for)
+                if constexpr (FUSED && SPH) sincos_bounded(yh * (float)(1 << b), e[2 * b], e[2 * b + 1]);
+                else sincos_enc(yh * (float)(1 << b), e[2 * b], e[2 * b + 1]);
+            }
             e[10] = yh;
             // ---------------- conditioning term c = W1[:, PE] PE(omega_i) -----------------------------
             if (!SPH) {   // split-fp16: the lane's 11 values are K slots of two K = 16 chunks (the 16-query kernels' SPLIT_PRO)
@@ -326,6 +402,10 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
                 if (h == 0) c[4 * 64 + n] = bo;
             }
         }
+        if constexpr (CaccLds<DOMAIN, FUSED>::on) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cslab[k * 64] = (f32x4){cacc[4 * k], cacc[4 * k + 1], cacc[4 * k + 2], cacc[4 * k + 3]};
+        }
         // bo = (loc0, loc1, ls0, ls1) disk | (loc, log_scale, mu, kappa_raw) spherical
         float kappa = 0.0f;
         if (SPH) kappa = softplus(bo[3]) + 1e-3f;
@@ -337,7 +417,10 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
         const bool reverse = FUSED ? (ph != 0) : reverse1;
         const float cstep = FUSED ? (ph ? -invT : invT) : cstep1;
         float* const out_pdf = (FUSED && ph) ? p.out_pdf2 : p.out_pdf;
-        if (FUSED && ph) load_dir(p.in_c);
+        if (FUSED && ph) {
+            bool v2;
+            load_dir(p.in_c, row_of(opaque(n), v2));
+        }
         if (FUSED && !ph) { xs = h ? xi1 : xi0; xo0 = xi0; xo1 = xi1; }
         // ---------------- initial state ------------------------------------------------------------
         auto fexp = [](float x) -> float { return __builtin_amdgcn_exp2f(x * kLog2e); };
@@ -388,7 +471,8 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
                 const double tf = (double)t * invT_d;
                 alpha = (float)(reverse ? 1.0 - tf : tf);
             }
-            // ---- layer 1: one fp16 MFMA, B slots [v_hi, v_lo, v_hi, w_hi, w_lo, w_hi, 0, 0] ----
+            // ---- layer 1: one fp16 MFMA, B slots [v_hi, v_lo, v_hi, v_lo, w_hi, w_lo, w_hi, w_lo] against A slots
+            //      [Wv_hi, Wv_hi, Wv_lo, Wv_lo, Ww_hi, Ww_hi, Ww_lo, Ww_lo]: all four products of the two-way splits ----
             float vin = xs, win = alpha, sp = 0.f, cp = 0.f;
             if (SPH) {
                 sincos_enc(xs, sp, cp);   // (meaningful in the upper half, whose xs is phi)
@@ -396,57 +480,53 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
                 win = h ? cp : alpha;
             }
             const float vh = hi_part(vin), wh = hi_part(win);
-            const _Float16 vh16 = (_Float16)vh, vl16 = (_Float16)(vin - vh), wh16 = (_Float16)wh, wl16 = (_Float16)(win - wh);
             const f16x2 zero2 = {(_Float16)0.0f, (_Float16)0.0f};
+            const f16x2 vp = {(_Float16)vh, (_Float16)(vin - vh)}, wp = {(_Float16)wh, (_Float16)(win - wh)};
             Frag b1;
-            b1.p[0] = (f16x2){vh16, vl16}; b1.p[1] = (f16x2){vh16, wh16}; b1.p[2] = (f16x2){wl16, wh16}; b1.p[3] = zero2;
+            b1.p[0] = vp; b1.p[1] = vp; b1.p[2] = wp; b1.p[3] = wp;
             const f16x8 a1 = *(reinterpret_cast<const f16x8*>(smem + LY::A1) + lane);
-            f32x16 z = mfma32(a1, b1.v, cacc);
+            f32x16 cin = cacc;
+            if constexpr (CaccLds<DOMAIN, FUSED>::on) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 t4 = cslab[k * 64];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cin[4 * k + r] = t4[r];
+                }
+            }
+            f32x16 z = mfma32(a1, b1.v, cin);
 
             float hv[16], gv[16];
             Frag bh[2], bl[2], gh[2], gl[2];
-            f32x16 U0, U1;
-            float gm[16];   // silu' of the middle layer: the fp32 factor of the bilinear form
+            f32x16 U0, U1;  // JAC: gm . U_i, U_i = the tangents' pre-activations at the middle layer, gm = its silu' (fp32)
+            float gm[16];
+            auto premul = [&] {   // ... multiplied in as soon as gm exists: 16 registers less across the last layer
+#pragma unroll
+                for (int v = 0; v < 16; ++v) { U0[v] *= gm[v]; U1[v] *= gm[v]; }
+            };
             if (!SPH) {
                 // ---- MIM, disk 25-32-32-32-2: U_i = F_i g1, R_j = G_j g3, J_ji = sum_k R_j[k] g2[k] U_i[k] (bsdfd.hip, block MIM)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) silu_grad_scaled(z[v], hv[v], gv[v]);
+                act16<JAC>(z, hv, gv);
                 split16(hv, bh, bl);
-                split16(gv, gh, gl);
-                {
-                    const Mat32 w2 = load_mat(smem, LY::WH, lane);
-                    z = mfma32(w2.h0, bh[0].v, zero16); z = mfma32(w2.h1, bh[1].v, z);
-                    z = mfma32(w2.h0, bl[0].v, z); z = mfma32(w2.h1, bl[1].v, z);
-                    z = mfma32(w2.l0, bh[0].v, z); z = mfma32(w2.l1, bh[1].v, z);
-                    const Mat32 f0 = load_mat(smem, LY::WF, lane), f1 = load_mat(smem, LY::WF + 4 * FR32, lane);
-                    U0 = mfma32(f0.h0, gh[0].v, zero16); U1 = mfma32(f1.h0, gh[0].v, zero16);
-                    U0 = mfma32(f0.h1, gh[1].v, U0); U1 = mfma32(f1.h1, gh[1].v, U1);
-                    U0 = mfma32(f0.h0, gl[0].v, U0); U1 = mfma32(f1.h0, gl[0].v, U1);
-                    U0 = mfma32(f0.h1, gl[1].v, U0); U1 = mfma32(f1.h1, gl[1].v, U1);
-                    U0 = mfma32(f0.l0, gh[0].v, U0); U1 = mfma32(f1.l0, gh[0].v, U1);
-                    U0 = mfma32(f0.l1, gh[1].v, U0); U1 = mfma32(f1.l1, gh[1].v, U1);
+                z = mm6(load_mat(smem, LY::WH, lane), bh, bl);
+                if constexpr (JAC) {
+                    split16(gv, gh, gl);
+                    mm6x2(load_mat(smem, LY::WF, lane), gh, gl, load_mat(smem, LY::WF + 4 * FR32, lane), gh, gl, U0, U1);
                 }
                 // hidden layer 2 (its silu' stays in fp32)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) silu_grad_scaled(z[v], hv[v], gm[v]);
+                act16<JAC>(z, hv, gm);
+                if constexpr (JAC) premul();
                 split16(hv, bh, bl);
-                {
-                    const Mat32 w3 = load_mat(smem, LY::WH + 4 * FR32, lane);
-                    z = mfma32(w3.h0, bh[0].v, zero16); z = mfma32(w3.h1, bh[1].v, z);
-                    z = mfma32(w3.h0, bl[0].v, z); z = mfma32(w3.h1, bl[1].v, z);
-                    z = mfma32(w3.l0, bh[0].v, z); z = mfma32(w3.l1, bh[1].v, z);
-                }
+                z = mm6(load_mat(smem, LY::WH + 4 * FR32, lane), bh, bl);
             } else {
                 // ---- MIMS, spherical 26-32-32-32-32-2: two forward-mode tangent layers, then the output fold (bsdfd.hip, block MIMS)
                 f32x16 zt0, zt1;
-                {
-                    // d(input)/dphi = (0, cos phi, -sin phi, 0): the upper lanes' slots [c_hi, c_lo, c_hi, -s_hi, -s_lo, -s_hi] against
-                    // the same A fragment; the lower lanes (theta, alpha) contribute nothing
+                if constexpr (JAC) {
+                    // d(input)/dphi = (0, cos phi, -sin phi, 0): the upper lanes' slots [c_hi, c_lo, c_hi, c_lo, -s_hi, -s_lo, -s_hi, -s_lo]
+                    // against the same A fragment; the lower lanes (theta, alpha) contribute nothing
                     Frag bt;
-                    bt.p[0] = h ? (f16x2){wh16, wl16} : zero2;
-                    bt.p[1] = h ? (f16x2){wh16, -vh16} : zero2;
-                    bt.p[2] = h ? (f16x2){-vl16, -vh16} : zero2;
-                    bt.p[3] = zero2;
+                    bt.p[0] = h ? wp : zero2; bt.p[1] = bt.p[0];
+                    bt.p[2] = h ? -vp : zero2; bt.p[3] = bt.p[2];
                     zt1 = mfma32(a1, bt.v, zero16);
                     const f32x4* Lwt0 = reinterpret_cast<const f32x4*>(smem + LY::WT0) + lane * 4;
 #pragma unroll
@@ -458,53 +538,36 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
                 }
 #pragma unroll
                 for (int layer = 0; layer < 2; ++layer) {
-                    float t0v[16], t1v[16];
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        silu_grad_scaled(z[v], hv[v], gv[v]);
-                        t0v[v] = zt0[v] * gv[v];
-                        t1v[v] = zt1[v] * gv[v];
-                    }
-                    Frag t0h[2], t0l[2], t1h[2], t1l[2];
+                    act16<JAC>(z, hv, gv);
                     split16(hv, bh, bl);
-                    split16(t0v, t0h, t0l);
-                    split16(t1v, t1h, t1l);
                     const Mat32 w = load_mat(smem, LY::WH + layer * 4 * FR32, lane);
-                    z = mfma32(w.h0, bh[0].v, zero16); z = mfma32(w.h1, bh[1].v, z);
-                    z = mfma32(w.h0, bl[0].v, z); z = mfma32(w.h1, bl[1].v, z);
-                    z = mfma32(w.l0, bh[0].v, z); z = mfma32(w.l1, bh[1].v, z);
-                    zt0 = mfma32(w.h0, t0h[0].v, zero16); zt1 = mfma32(w.h0, t1h[0].v, zero16);
-                    zt0 = mfma32(w.h1, t0h[1].v, zt0); zt1 = mfma32(w.h1, t1h[1].v, zt1);
-                    zt0 = mfma32(w.h0, t0l[0].v, zt0); zt1 = mfma32(w.h0, t1l[0].v, zt1);
-                    zt0 = mfma32(w.h1, t0l[1].v, zt0); zt1 = mfma32(w.h1, t1l[1].v, zt1);
-                    zt0 = mfma32(w.l0, t0h[0].v, zt0); zt1 = mfma32(w.l0, t1h[0].v, zt1);
-                    zt0 = mfma32(w.l1, t0h[1].v, zt0); zt1 = mfma32(w.l1, t1h[1].v, zt1);
-                }
-                U0 = zt0; U1 = zt1;
-                // hidden layer 3 (its silu' stays in fp32)
+                    z = mm6(w, bh, bl);
+                    if constexpr (JAC) {
+                        float t0v[16], t1v[16];
 #pragma unroll
-                for (int v = 0; v < 16; ++v) silu_grad_scaled(z[v], hv[v], gm[v]);
-                split16(hv, bh, bl);
-                {
-                    const Mat32 w4 = load_mat(smem, LY::WH + 2 * 4 * FR32, lane);
-                    z = mfma32(w4.h0, bh[0].v, zero16); z = mfma32(w4.h1, bh[1].v, z);
-                    z = mfma32(w4.h0, bl[0].v, z); z = mfma32(w4.h1, bl[1].v, z);
-                    z = mfma32(w4.l0, bh[0].v, z); z = mfma32(w4.l1, bh[1].v, z);
+                        for (int v = 0; v < 16; ++v) {
+                            t0v[v] = zt0[v] * gv[v];
+                            t1v[v] = zt1[v] * gv[v];
+                        }
+                        Frag t0h[2], t0l[2], t1h[2], t1l[2];
+                        split16(t0v, t0h, t0l);
+                        split16(t1v, t1h, t1l);
+                        mm6x2(w, t0h, t0l, w, t1h, t1l, zt0, zt1);
+                    }
                 }
+                if constexpr (JAC) { U0 = zt0; U1 = zt1; }
+                // hidden layer 3 (its silu' stays in fp32)
+                act16<JAC>(z, hv, gm);
+                if constexpr (JAC) premul();
+                split16(hv, bh, bl);
+                z = mm6(load_mat(smem, LY::WH + 2 * 4 * FR32, lane), bh, bl);
             }
             // ---- last hidden layer -> R0, R1 (MFMA), v (fp32 VALU dot over the lane's 16 units + one swap) ----
-#pragma unroll
-            for (int v = 0; v < 16; ++v) silu_grad_scaled(z[v], hv[v], gv[v]);
-            split16(gv, gh, gl);
+            act16<JAC>(z, hv, gv);
             f32x16 R0, R1;
-            {
-                const Mat32 g0 = load_mat(smem, LY::WG, lane), g1 = load_mat(smem, LY::WG + 4 * FR32, lane);
-                R0 = mfma32(g0.h0, gh[0].v, zero16); R1 = mfma32(g1.h0, gh[0].v, zero16);
-                R0 = mfma32(g0.h1, gh[1].v, R0); R1 = mfma32(g1.h1, gh[1].v, R1);
-                R0 = mfma32(g0.h0, gl[0].v, R0); R1 = mfma32(g1.h0, gl[0].v, R1);
-                R0 = mfma32(g0.h1, gl[1].v, R0); R1 = mfma32(g1.h1, gl[1].v, R1);
-                R0 = mfma32(g0.l0, gh[0].v, R0); R1 = mfma32(g1.l0, gh[0].v, R1);
-                R0 = mfma32(g0.l1, gh[1].v, R0); R1 = mfma32(g1.l1, gh[1].v, R1);
+            if constexpr (JAC) {
+                split16(gv, gh, gl);
+                mm6x2(load_mat(smem, LY::WG, lane), gh, gl, load_mat(smem, LY::WG + 4 * FR32, lane), gh, gl, R0, R1);
             }
             {
                 const f32x4* Lwo = reinterpret_cast<const f32x4*>(smem + LY::WOUT + h * 128);
@@ -519,15 +582,13 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
                 swap32(pv0, pv1);            // lower: v0 over the lane pair | upper: v1
                 xs = fmaf(cstep, pv0 + pv1, xs);
             }
-            // ---- J_ji = sum_k R_j[k] gm[k] U_i[k] over the lane's 16 units, then over the query's 2 lanes; det(I + c J) ----
-            {
+            // ---- J_ji = sum_k R_j[k] (gm[k] U_i[k]) over the lane's 16 units, then over the query's 2 lanes; det(I + c J) ----
+            if constexpr (JAC) {
                 f32x2 ja2 = {0.f, 0.f}, jb2 = ja2, jc2 = ja2, jd2 = ja2;  // J00, J11, J01, J10
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const f32x2 gg2 = {gm[2 * k], gm[2 * k + 1]};
                     const f32x2 r0 = {R0[2 * k], R0[2 * k + 1]}, r1 = {R1[2 * k], R1[2 * k + 1]};
-                    const f32x2 u0 = gg2 * (f32x2){U0[2 * k], U0[2 * k + 1]};
-                    const f32x2 u1 = gg2 * (f32x2){U1[2 * k], U1[2 * k + 1]};
+                    const f32x2 u0 = {U0[2 * k], U0[2 * k + 1]}, u1 = {U1[2 * k], U1[2 * k + 1]};   // (gm . U_i)
                     ja2 = __builtin_elementwise_fma(r0, u0, ja2);
                     jc2 = __builtin_elementwise_fma(r0, u1, jc2);
                     jd2 = __builtin_elementwise_fma(r1, u0, jd2);
@@ -543,6 +604,7 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
                 float pr = w * o, pr2 = pr;
                 swap32(pr, pr2);              // lower: pr = w00 w11, pr2 = o01 o10
                 const float det = pr - pr2;   // valid in the lower half (the lanes that write the results)
+                // forward: the reference divides (tmp_J /= J); v_rcp_f32 (1 ulp) * acc differs from the IEEE quotient by <= 2 ulp
                 if (reverse) acc *= det; else acc *= __builtin_amdgcn_rcpf(det);
             }
         }
@@ -554,11 +616,13 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
         if (op == OP_SAMPLE) pdf = p0 * acc;
         else if (op == OP_PDF) pdf = base_pdf(x0, x1) * acc;
 
-        const bool writer = valid && h == 0;
+        bool valid_e;
+        const long long qe = row_of(opaque(n), valid_e);
+        const bool writer = valid_e && h == 0;
         if (p.io == IO_OPERATOR) {
             if (writer) {
-                if (op != OP_PDF) reinterpret_cast<float2*>(p.out_x)[qi] = make_float2(x0, x1);
-                if (op != OP_SAMPLES_ONLY) out_pdf[qi] = pdf;
+                if (op != OP_PDF) reinterpret_cast<float2*>(p.out_x)[qe] = make_float2(x0, x1);
+                if (op != OP_SAMPLES_ONLY) out_pdf[qe] = pdf;
             }
         } else if (op == OP_SAMPLE) {
             float ox, oy, oz, pdf_sa;
@@ -579,8 +643,8 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
                 pdf_sa = pdf * inv;
             }
             if (writer) {
-                p.out_x[qi * 3 + 0] = ox; p.out_x[qi * 3 + 1] = oy; p.out_x[qi * 3 + 2] = oz;
-                out_pdf[qi] = pdf_sa;
+                p.out_x[qe * 3 + 0] = ox; p.out_x[qe * 3 + 1] = oy; p.out_x[qe * 3 + 2] = oz;
+                out_pdf[qe] = pdf_sa;
             }
         } else {
             float pdf_sa;
@@ -595,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void flow_kernel32(const KParams p) {
                     pdf_sa = pdf * inv;
                 }
             }
-            if (writer) out_pdf[qi] = pdf_sa;
+            if (writer) out_pdf[qe] = pdf_sa;
         }
         }
         if (FUSED && ++ph < nphase) goto next_phase;
@@ -644,7 +708,7 @@ std::vector<char> build_image32_t(const bsdfd_desc& d) {
                     H(off)[(size_t)((2 + c) * 64 + l) * 8 + j] = f16_bits((float)(v - (double)hi));
                 }
     };
-    // layer-1 state fragment: slots [Wv_hi, Wv_hi, Wv_lo, Ww_hi, Ww_hi, Ww_lo, 0, 0]
+    // layer-1 state fragment: slots [Wv_hi, Wv_hi, Wv_lo, Wv_lo, Ww_hi, Ww_hi, Ww_lo, Ww_lo] (and the same columns as fp32 A operands)
     for (int l = 0; l < 64; ++l) {
         const int hh = l >> 5, row = l & 31;
         float wv, ww;
@@ -655,8 +719,9 @@ std::vector<char> build_image32_t(const bsdfd_desc& d) {
             wv = w_in[(size_t)row * IN + (hh == 0 ? 0 : 1)];
             ww = w_in[(size_t)row * IN + (hh == 0 ? 3 : 2)];
         }
-        const float s[8] = {f16_rnd(wv), f16_rnd(wv), wv - f16_rnd(wv), f16_rnd(ww), f16_rnd(ww), ww - f16_rnd(ww), 0.f, 0.f};
+        const float s[8] = {f16_rnd(wv), f16_rnd(wv), wv - f16_rnd(wv), wv - f16_rnd(wv), f16_rnd(ww), f16_rnd(ww), ww - f16_rnd(ww), ww - f16_rnd(ww)};
         for (int j = 0; j < 8; ++j) H(LY::A1)[(size_t)l * 8 + j] = f16_bits(s[j]);
+
     }
     if (SPH)
         for (int l = 0; l < 64; ++l)
@@ -718,9 +783,23 @@ std::vector<char> bsdfd_build_image32(const bsdfd_desc& d) {
     return d.domain == BSDFD_DOMAIN_DISK ? build_image32_t<BSDFD_DOMAIN_DISK>(d) : build_image32_t<BSDFD_DOMAIN_SPHERICAL>(d);
 }
 
+int bsdfd_kernel32_lds_bytes(int domain, int mode) {
+    if (mode == 2)
+        return domain == BSDFD_DOMAIN_DISK ? L32<BSDFD_DOMAIN_DISK>::TOTAL + 4 * CaccLds<BSDFD_DOMAIN_DISK, true>::slab
+                                           : L32<BSDFD_DOMAIN_SPHERICAL>::TOTAL + 4 * CaccLds<BSDFD_DOMAIN_SPHERICAL, true>::slab;
+    return domain == BSDFD_DOMAIN_DISK ? L32<BSDFD_DOMAIN_DISK>::TOTAL + 4 * CaccLds<BSDFD_DOMAIN_DISK, false>::slab
+                                       : L32<BSDFD_DOMAIN_SPHERICAL>::TOTAL + 4 * CaccLds<BSDFD_DOMAIN_SPHERICAL, false>::slab;
+}
+
 const void* bsdfd_kernel32(int domain, int mode) {
-    if (mode == 1)
-        return domain == BSDFD_DOMAIN_DISK ? reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_DISK, false>)
-                                           : reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_SPHERICAL, false>);
+    const bool disk = domain == BSDFD_DOMAIN_DISK;
+    switch (mode) {
+        case 0: return disk ? reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_DISK, false, false>)
+                            : reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_SPHERICAL, false, false>);
+        case 1: return disk ? reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_DISK, true, false>)
+                            : reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_SPHERICAL, true, false>);
+        case 2: return disk ? reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_DISK, true, true>)
+                            : reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_SPHERICAL, true, true>);
+    }
     return nullptr;
 }

@@ -80,6 +80,8 @@ class FlowSampler:
         p = C.c_int32()
         _lib.check(L.bsdfd_get_info(h, None, None, None, C.byref(p)))
         self.precision = {v: k for k, v in _lib.PRECISIONS.items()}[p.value]
+        _lib.check(L.bsdfd_get_tile(h, C.byref(p)))
+        self.tile = int(p.value)   # queries per wave tile of the kernels in effect (16 | 32)
 
     def close(self):
         if getattr(self, "_h", None):

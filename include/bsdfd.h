@@ -93,6 +93,9 @@ void bsdfd_destroy(bsdfd_handle h);
 int bsdfd_get_info(bsdfd_handle h, int32_t* domain, int32_t* width, int32_t* n_hidden,
                    int32_t* precision);
 int64_t bsdfd_flops_per_query(bsdfd_handle h, int32_t T);
+/* Queries per wave64 tile of the kernels this handle launches (16 or 32, see bsdfd_desc.tile): the granularity of the opaque
+ * per-query context below.  No counterpart in the reference. */
+int bsdfd_get_tile(bsdfd_handle h, int32_t* tile);
 
 /* network_sampling_disk / network_sampling_spherical
  * (rendering/utils/mlp_brdf_sampling.py:17-51, :106-140).

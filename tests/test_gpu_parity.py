@@ -25,12 +25,18 @@ def _dev():
     return torch.device("cuda", 0)
 
 
-@pytest.fixture(autouse=True, params=["ctypes", "torch"])
+@pytest.fixture(autouse=True, params=["ctypes", "torch", "ctypes-tile16"])
 def host_binding(request, monkeypatch):
     """Every parity test of this module runs through BOTH host shims over the C ABI: the ctypes binding and the
-    PyTorch-ROCm operator library torch.ops.bsdfd.* (csrc/torch_ops.cpp)."""
-    monkeypatch.setenv("BSDFD_HOST_BINDING", request.param)
-    yield request.param
+    PyTorch-ROCm operator library torch.ops.bsdfd.* (csrc/torch_ops.cpp) — and, third, with $BSDFD_TILE=16: the 16-query-tile
+    kernels (csrc/bsdfd.hip) for the nets whose default is the 32-query-tile family (csrc/flow32.hip; bsdfd_desc.tile)."""
+    binding, _, tile = request.param.partition("-tile")
+    monkeypatch.setenv("BSDFD_HOST_BINDING", binding)
+    if tile:
+        monkeypatch.setenv("BSDFD_TILE", tile)
+    else:
+        monkeypatch.delenv("BSDFD_TILE", raising=False)
+    yield binding
 
 
 def _sampler(fw, precision):
@@ -614,7 +620,10 @@ def test_per_query_context_gives_bit_identical_results(stem, variant, n):
     wi, wl = dirs(0.05), dirs(-1.0 if variant else 0.02)
     T = 4 if fw.domain == 0 else 8
     ctx = s.new_context(n)
-    assert ctx.numel() * 4 == ((n + 15) // 16 + 1) * ((fw.width // 16) * 64 + 16) * 16
+    # (opaque; 144 B per query for the 32-wide nets in either tiling: per 16-query tile NM x 64 + 16 records of 16 B, per 32-query
+    #  tile 4 x 64 + 32, plus one spare tile per segment)
+    per_tile = ((fw.width // 16) * 64 + 16) * 16 if s.tile == 16 else (4 * 64 + 32) * 16
+    assert ctx.numel() * 4 == ((n + s.tile - 1) // s.tile + 1) * per_tile
     ctx.fill_(float("nan"))
     for x0 in (None, _t(np.tile(g["x0"], (n // 2048 + 1, 1))[:n])):
         wo, p = s.plugin_sample(wi, x0, T=T, variant=variant, seed=3, offset=11)

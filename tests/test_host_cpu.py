@@ -347,9 +347,10 @@ def test_asynchronous_lds_reads_are_not_touched_before_their_wait():
                        timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(", 0 violations") == 8 and "25 asynchronous" in r.stdout and "21 asynchronous" in r.stdout
-    assert "MFMA results consumed before their wait states: 0 of 54 kernels" in r.stdout
-    assert "lane swaps of a register written fewer than 2 wait states earlier: 0 of 54 kernels" in r.stdout
-    assert r.stdout.count("occupancy ") == 4 and "LOST" not in r.stdout, r.stdout   # 3 / 3 / 4 / 2 waves/SIMD of the tracked kernels
+    assert "census of the two translation units: 0 problem(s)" in r.stdout
+    assert "MFMA results consumed before their wait states: 0 of 60 kernels" in r.stdout
+    assert "lane swaps of a register written fewer than 2 wait states earlier: 0 of 60 kernels" in r.stdout
+    assert r.stdout.count("occupancy ") == 8 and "LOST" not in r.stdout, r.stdout   # waves/SIMD of the tracked kernels
 
 
 _ASM_OK = """
@@ -460,6 +461,110 @@ def test_build_refuses_to_ship_when_mfma_results_are_consumed_too_early(tmp_path
     assert not os.path.exists(out)
 
 
+def _product_asm():
+    """Device assembly of the product build (kept by _lib.build() under build/asm/)."""
+    import shutil
+    if not shutil.which("hipcc"):
+        pytest.skip("needs hipcc")
+    from bsdf_diffusion_sampling_amd import _lib
+    paths = [os.path.join(_lib.ASM_CACHE_DIR, f) for f in ("bsdfd.s", "flow32.s")]
+    if not all(os.path.exists(q) and os.path.getmtime(q) >= os.path.getmtime(_lib.LIB_PATH) - 600 for q in paths):
+        _lib.build(force=True)
+    return paths
+
+
+def test_assembly_census_fails_closed(tmp_path):
+    """`_check_asm('/tmp/empty.s')` used to be "no violations".  The census (`_asmcheck.verify_census`) is
+    what `_lib.build()` now holds the assembly to before it trusts "0 violations": the product build passes it; an empty file,
+    renamed kernel labels, asynchronous reads under another mnemonic, a kernel without recognisable MFMAs, missing metadata
+    and scratch memory are each reported."""
+    from bsdf_diffusion_sampling_amd import _asmcheck as A
+    paths = _product_asm()
+    assert A.verify_census(paths, "async") == []
+    exp = A.expected_flow_kernels("async")
+    assert len(exp) == 60 and sum(1 for v in exp.values() if v["async"]) == 8      # 54 in csrc/bsdfd.hip + 6 in csrc/flow32.hip
+    assert all(v == {"async": 0, "waits": 0} for v in A.expected_flow_kernels("plain").values())
+    empty = tmp_path / "empty.s"
+    empty.write_text("")
+    assert len(A.verify_census([str(empty)], "async")) == 60                        # (a) nothing found
+    text = open(paths[0]).read()
+    renamed = tmp_path / "renamed.s"
+    renamed.write_text(text.replace("flow_kernel", "flowkernel"))
+    got = A.verify_census([str(renamed), paths[1]], "async")
+    assert len(got) == 54 and all("not found" in m for m in got)                   # (b) labels the parser does not know
+    spelled = tmp_path / "spelled.s"
+    spelled.write_text(text.replace("ds_read_b128", "ds_load_b128"))
+    got = A.verify_census([str(spelled), paths[1]], "async")
+    assert len(got) == 8 and all("0 asynchronous ds_read_b128" in m for m in got)  # (c) the reads it must verify are invisible
+    assert A.verify_census([str(spelled)], "async", only="flow_kernelI") == got     # ... which sends build() to the fallback variant
+    nomfma = tmp_path / "nomfma.s"
+    nomfma.write_text(text.replace("v_mfma_", "v_wmma_"))
+    assert sum("no MFMA instruction recognised" in m for m in A.verify_census([str(nomfma), paths[1]], "async")) == 54
+    nometa = tmp_path / "nometa.s"
+    nometa.write_text(text.replace(".vgpr_count:", ".vgprs:"))
+    assert sum("metadata not found" in m for m in A.verify_census([str(nometa), paths[1]], "async")) == 54
+    scratch = tmp_path / "scratch.s"
+    scratch.write_text(text.replace(".private_segment_fixed_size: 0", ".private_segment_fixed_size: 68", 1))
+    got = A.verify_census([str(scratch), paths[1]], "async")
+    assert len(got) == 1 and "68 B of scratch" in got[0]
+    extra = tmp_path / "extra.s"
+    extra.write_text(text.replace("flow_kernelILi0ELi2ELi2ELb1ELi3ELb0EE", "flow_kernelILi0ELi2ELi2ELb1ELi5ELb0EE"))
+    got = A.verify_census([str(extra), paths[1]], "async")
+    assert any("unexpected flow kernel" in m for m in got) and any("not found" in m for m in got)
+
+
+def test_asmcheck_mfma_operands_in_agprs_and_as_matrix_inputs():
+    """an MFMA whose destination the parser does not understand is a finding, not a skip; AGPR destinations are
+    tracked; a result consumed as SrcA / SrcB of a later MFMA needs the wait states (only an unchanged SrcC is interlocked)."""
+    from bsdf_diffusion_sampling_amd import _asmcheck as A
+    key = "flow_kernelILi1ELi2ELi2ELb1ELi4ELb0E"
+    head = "_ZN12_GLOBAL__N_111flow_kernelILi1ELi2ELi2ELb1ELi4ELb0EEEvNS_7KParamsE:\n"
+    tail = "\ts_endpgm\n"
+    weird = head + "\tv_mfma_f32_16x16x32_f16 acc[0:3], v[26:29], v[0:3], 0\n" + tail
+    n, bad = A.check_mfma_hazards_lines(weird.splitlines(), key)
+    assert n == 1 and len(bad) == 1 and "not understood" in bad[0]
+    agpr = head + "\tv_mfma_f32_16x16x32_f16 a[0:3], v[26:29], v[0:3], 0\n\tv_accvgpr_read_b32 v5, a2\n" + tail
+    n, bad = A.check_mfma_hazards_lines(agpr.splitlines(), key)
+    assert n == 1 and len(bad) == 1 and "after 0 wait states (needs 8)" in bad[0]
+    assert A.check_mfma_hazards_lines(agpr.replace("\tv_accvgpr", "\ts_nop 7\n\tv_accvgpr").splitlines(), key) == (1, [])
+    src_b = head + "\tv_mfma_f32_16x16x32_f16 v[10:13], v[26:29], v[0:3], 0\n\tv_mfma_f32_16x16x32_f16 v[40:43], v[26:29], v[10:13], 0\n" + tail
+    n, bad = A.check_mfma_hazards_lines(src_b.splitlines(), key)
+    assert n == 2 and len(bad) == 1 and "as a matrix operand after 0 wait states (needs 8)" in bad[0]
+    partial_c = src_b.replace("v[40:43], v[26:29], v[10:13], 0", "v[12:15], v[26:29], v[30:33], v[12:15]")
+    assert "as a matrix operand" in A.check_mfma_hazards_lines(partial_c.splitlines(), key)[1][0]
+    same_c = src_b.replace("v[40:43], v[26:29], v[10:13], 0", "v[10:13], v[26:29], v[30:33], v[10:13]")
+    assert A.check_mfma_hazards_lines(same_c.splitlines(), key) == (2, [])
+    # a register the next MFMA has rewritten belongs to THAT MFMA: the first one's walk does not claim it any more
+    taken = head + ("\tv_mfma_f32_16x16x4_f32 v[56:59], v1, v2, 0\n\tv_mfma_f32_16x16x4_f32 v[54:57], v3, v4, v[56:59]\n"
+                    "\tv_mfma_f32_16x16x4_f32 v[54:57], v5, v6, v[54:57]\n\ts_nop 7\n\ts_nop 1\n\tv_mov_b32_e32 v0, v55\n") + tail
+    assert A.check_mfma_hazards_lines(taken.splitlines(), key) == (3, [])
+
+
+def test_build_refuses_an_unverifiable_compilation_unless_overridden(tmp_path, monkeypatch, capsys):
+    """The census failing (here: a doctored verdict) aborts the build and writes every finding next to the library;
+    BSDFD_ALLOW_UNVERIFIED_BUILD=1 ships it, marked in the build info and in bsdfd_version()."""
+    import ctypes as C
+    import shutil
+    if not shutil.which("hipcc"):
+        pytest.skip("needs hipcc")
+    from bsdf_diffusion_sampling_amd import _lib
+    real = _lib._census
+    monkeypatch.setattr(_lib, "_census", lambda paths, variant, only=None: real(paths, variant, only=only) if only else
+                        ["flow kernel flow_kernelILi0ELi2ELi2ELb1ELi3ELb0EE not found in the assembly"])
+    out = str(tmp_path / "libbsdfd_unverified.so")
+    with pytest.raises(RuntimeError, match="refusing to ship"):
+        _lib.build(force=True, lib_path=out)
+    assert not os.path.exists(out) and "not found in the assembly" in open(out + ".asmcheck.txt").read()
+    monkeypatch.setenv("BSDFD_ALLOW_UNVERIFIED_BUILD", "1")
+    assert _lib.build(force=True, lib_path=out) == out
+    assert _lib.build_info(out)["unverified"] is True and "SHIPPING IT ANYWAY" in capsys.readouterr().out
+    import torch  # noqa: F401
+    L = C.CDLL(out)
+    L.bsdfd_version.restype = C.c_char_p
+    assert b"UNVERIFIED BUILD" in L.bsdfd_version()
+    assert _lib.build_info().get("unverified") is False and b"UNVERIFIED" not in _lib.lib().bsdfd_version()
+
+
 def test_build_falls_back_to_compiler_managed_lds_reads_when_the_asm_check_fails(tmp_path, monkeypatch, capsys):
     """_lib.build() verifies the assembly of ITS OWN compilation of csrc/bsdfd.hip and, when an instruction touches the
     destination of an asynchronous LDS read before its wait, rebuilds with -DBSDFD_NO_ASYNC_LDS instead of shipping a library
@@ -498,10 +603,11 @@ def test_committed_profiles_match_the_kernel_source():
     refresh would silently carry stale figures").  The committed tree must never be in that state."""
     import hashlib
     import json
-    sha = hashlib.sha256(open(os.path.join(ROOT, "bsdf_diffusion_sampling_amd", "csrc", "bsdfd.hip"), "rb").read()).hexdigest()
+    from bsdf_diffusion_sampling_amd import _lib
+    sha = _lib.kernel_source_sha256()
     for f in ("isa_mix_latest.json", "pmc_latest.json"):
         meta = json.load(open(os.path.join(ROOT, "profiles", f))).get("_meta", {})
-        assert meta.get("kernel_source_sha256") == sha, f"profiles/{f} was taken with another csrc/bsdfd.hip: re-run tools/profile.sh / tools/isa_mix.py --profile"
+        assert meta.get("kernel_source_sha256") == sha, f"profiles/{f} was taken with other flow-kernel sources: re-run tools/profile.sh / tools/isa_mix.py --profile"
     sys.path.insert(0, ROOT)
     import bench
     for wl in ("disk_1Mi_T8", "spherical_16Mi_T8"):

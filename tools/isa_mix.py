@@ -49,11 +49,42 @@ sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))
 from bsdf_diffusion_sampling_amd._asmcheck import check_async_lines, check_file_mfma, kernel_body, loops, mix  # noqa: E402
 
 
-KERNEL_OF_WORKLOAD = {  # bench.py workload -> mangled-name fragment of its flow kernel (split3, Jacobian)
-    "disk_1Mi_T8": "flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E",
-    "disk_1Mi_T4": "flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E",
-    "spherical_16Mi_T8": "flow_kernelILi1ELi2ELi2ELb1ELi4ELb0E",
+KERNEL_OF_WORKLOAD = {  # bench.py workload -> mangled-name fragment of its flow kernel (split3, Jacobian; the library's default tile)
+    "disk_1Mi_T8": "flow_kernel32ILi0ELb1ELb0E",
+    "disk_1Mi_T4": "flow_kernel32ILi0ELb1ELb0E",
+    "spherical_16Mi_T8": "flow_kernel32ILi1ELb1ELb0E",
+    "teacher_64x6_4Mi_T128": "flow_kernelILi1ELi4ELi3ELb0ELi6ELb0E",
+    "complex64_1Mi_T8": "flow_kernelILi1ELi4ELi2ELb1ELi6ELb0E",
+    # the 16-query-tile kernels of the same nets (bsdfd_desc.tile = 16), for comparison
+    "disk_1Mi_T8@tile16": "flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E",
+    "spherical_16Mi_T8@tile16": "flow_kernelILi1ELi2ELi2ELb1ELi4ELb0E",
 }
+
+
+def tile_of(key):
+    """Queries per wave tile of a kernel (name fragment): 32 for csrc/flow32.hip, 16 for csrc/bsdfd.hip."""
+    return 32 if "flow_kernel32" in key else 16
+
+
+def compile_asm(td):
+    """Device assembly of the two flow-kernel translation units -> {"bsdfd": path, "flow32": path} (compiled in parallel)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs, out = [], {}
+    for stem in ("bsdfd", "flow32"):
+        out[stem] = os.path.join(td, stem + ".s")
+        procs.append(subprocess.Popen(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-value",
+                                       "-Wno-pass-failed", "-Wno-unused-command-line-argument", "-I", os.path.join(root, "include"),
+                                       os.path.join(root, "bsdf_diffusion_sampling_amd", "csrc", stem + ".hip"), "-o", out[stem]]))
+    for pr in procs:
+        if pr.wait() != 0:
+            raise RuntimeError("hipcc failed")
+    return out
+
+
+def asm_of(paths, key):
+    return paths["flow32" if "flow_kernel32" in key else "bsdfd"]
 
 
 def profile(out_path):
@@ -64,16 +95,13 @@ def profile(out_path):
     import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as td:
-        asm = os.path.join(td, "bsdfd.s")
-        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-value",
-                        "-Wno-pass-failed", "-Wno-unused-command-line-argument", "-I", os.path.join(root, "include"),
-                        os.path.join(root, "bsdf_diffusion_sampling_amd", "csrc", "bsdfd.hip"), "-o", asm], check=True)
-        res = {w: model(asm, k) for w, k in KERNEL_OF_WORKLOAD.items()}
-    import hashlib
-    src = os.path.join(root, "bsdf_diffusion_sampling_amd", "csrc", "bsdfd.hip")
+        paths = compile_asm(td)
+        res = {w: model(asm_of(paths, k), k) for w, k in KERNEL_OF_WORKLOAD.items()}
+    sys.path.insert(0, root)
+    from bsdf_diffusion_sampling_amd import _lib
     git = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-    dirty = bool(subprocess.run(["git", "-C", root, "status", "--porcelain", "--", src], capture_output=True, text=True).stdout.strip())
-    res["_meta"] = {"kernel_source_sha256": hashlib.sha256(open(src, "rb").read()).hexdigest(), "git": git + ("+dirty" if dirty else ""),
+    dirty = bool(subprocess.run(["git", "-C", root, "status", "--porcelain", "--", *_lib.KERNEL_SOURCES], capture_output=True, text=True).stdout.strip())
+    res["_meta"] = {"kernel_source_sha256": _lib.kernel_source_sha256(), "git": git + ("+dirty" if dirty else ""),
                     "tool": "tools/isa_mix.py --profile", "cost_model": "additive: sum of VALU costs + matrix-pipe time of the MFMAs, round 4 (see COST in tools/isa_mix.py)"}
     json.dump(res, open(out_path, "w"), indent=1)
     print(f"wrote {out_path}")
@@ -104,10 +132,8 @@ def main():
         import tempfile
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         with tempfile.TemporaryDirectory() as td:
-            asm = os.path.join(td, "bsdfd.s")
-            subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-value",
-                            "-Wno-pass-failed", "-Wno-unused-command-line-argument", "-I", os.path.join(root, "include"),
-                            os.path.join(root, "bsdf_diffusion_sampling_amd", "csrc", "bsdfd.hip"), "-o", asm], check=True)
+            paths = compile_asm(td)
+            asm = paths["bsdfd"]
             rc = 0
             for key in ("flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E", "flow_kernelILi0ELi2ELi3ELb1ELi3ELb0E",    # disk 32x3: split3, f16
                         "flow_kernelILi0ELi2ELi2ELb1ELi3ELb1E", "flow_kernelILi0ELi2ELi3ELb1ELi3ELb1E",    # ... fused sample+pdf
@@ -118,7 +144,14 @@ def main():
                 for b in bad:
                     print("  ", b)
                 rc |= bool(bad) or n == 0
+            from bsdf_diffusion_sampling_amd._asmcheck import verify_census
+            problems = verify_census([paths["bsdfd"], paths["flow32"]], "async")
+            print(f"census of the two translation units: {len(problems)} problem(s)")
+            for m in problems[:8]:
+                print("  ", m)
+            rc |= bool(problems)
             hz = check_file_mfma(asm)
+            hz.update(check_file_mfma(paths["flow32"]))
             n_bad = sum(1 for _, b in hz.values() if b)
             print(f"MFMA results consumed before their wait states: {n_bad} of {len(hz)} kernels, {sum(n for n, _ in hz.values())} MFMAs checked")
             for k, (_, b) in hz.items():
@@ -128,9 +161,13 @@ def main():
             # occupancy of the kernels behind the tracked workloads (waves/SIMD the VGPR allocation allows): a prologue edit shared
             # by all instantiations once took the teacher sampler from 4 to 3 waves unnoticed (round 4, -4 %)
             from bsdf_diffusion_sampling_amd._asmcheck import kernel_meta
-            lines = open(asm).read().splitlines()
-            for name, key, want in (("disk 32x3 split3 (disk_1Mi_T8 / T4)", "flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E", 3),
-                                    ("spherical 32x4 split3 (spherical_16Mi_T8)", "flow_kernelILi1ELi2ELi2ELb1ELi4ELb0E", 3),
+            lines = open(asm).read().splitlines() + open(paths["flow32"]).read().splitlines()
+            for name, key, want in (("disk 32x3 split3, 32-query tiles (disk_1Mi_T8 / T4)", "flow_kernel32ILi0ELb1ELb0E", 3),
+                                    ("spherical 32x4 split3, 32-query tiles (spherical_16Mi_T8)", "flow_kernel32ILi1ELb1ELb0E", 3),
+                                    ("disk 32x3 fused sample+pdf, 32-query tiles", "flow_kernel32ILi0ELb1ELb1E", 3),
+                                    ("spherical 32x4 fused sample+pdf, 32-query tiles", "flow_kernel32ILi1ELb1ELb1E", 2),
+                                    ("disk 32x3 split3, 16-query tiles", "flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E", 3),
+                                    ("spherical 32x4 split3, 16-query tiles", "flow_kernelILi1ELi2ELi2ELb1ELi4ELb0E", 3),
                                     ("teacher 64x6 f16, no Jacobian", "flow_kernelILi1ELi4ELi3ELb0ELi6ELb0E", 4),
                                     ("64x6 split3 with Jacobian (complex64_1Mi_T8)", "flow_kernelILi1ELi4ELi2ELb1ELi6ELb0E", 2)):
                 v = kernel_meta(lines, key).get("vgpr_count", 0)
@@ -139,6 +176,7 @@ def main():
                 rc |= waves < want
             from bsdf_diffusion_sampling_amd._asmcheck import check_file_swap
             sw = check_file_swap(asm)
+            sw.update(check_file_swap(paths["flow32"]))
             n_bad = sum(1 for _, b in sw.values() if b)
             print(f"lane swaps of a register written fewer than 2 wait states earlier: {n_bad} of {len(sw)} kernels, {sum(n for n, _ in sw.values())} swaps checked")
             rc |= bool(n_bad)
@@ -172,7 +210,7 @@ def model(path, key):
                         meta[f] = int(m.group(1))
             break
     res = {
-        "kernel": key, "loop_lines": best[1] - best[0] + 1,
+        "kernel": key, "tile_queries": tile_of(key), "loop_lines": best[1] - best[0] + 1,
         "mfma": mfma, "n_mfma": sum(mfma.values()),
         "n_valu": sum(valu.values()),
         "valu_top": dict(sorted(valu.items(), key=lambda kv: -kv[1])[:14]),

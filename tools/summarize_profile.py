@@ -111,8 +111,9 @@ def main():
     if "hbm_bytes_per_launch" in out:
         import hashlib
         import subprocess
-        kernel_src = os.path.join(ROOT, "bsdf_diffusion_sampling_amd", "csrc", "bsdfd.hip")
-        sha = hashlib.sha256(open(kernel_src, "rb").read()).hexdigest()
+        sys.path.insert(0, ROOT)
+        from bsdf_diffusion_sampling_amd import _lib
+        sha = _lib.kernel_source_sha256()
         git = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
         meta = latest.get("_meta", {})
         if meta.get("kernel_source_sha256") != sha:   # entries of an older kernel do not survive next to new ones
