@@ -318,7 +318,7 @@ class SingleMaterial:
         assert torch.allclose((w * w).sum(1), torch.ones_like(w[:, 0]), atol=1e-4)
 
     def config(self):
-        return {"material": self.material, "domain": self.domain, "euler_steps": self.T,
+        return {"material": self.material, "domain": self.domain, "euler_steps": self.T, "tile_queries": self.smp.tile,
                 "api": "plugin-level sample()+pdf() (warp + guards fused), in-kernel Philox RNG",
                 "per_query_context": self.ctx is not None}
 
@@ -360,7 +360,8 @@ class MixedMaterials:
         # one scatter of the three results back to the callers' lane order
         tab = self.tab
         if self.pipe is not None:
-            self.wave = self.pipe.push(self.ids, self.wi, seed=1000 + k, offset=self.rank * self.n_local, ctx=self.ctx)
+            # (ids / wi are resident, fixed inputs: ready=False — nothing to order the side stream behind)
+            self.wave = self.pipe.push(self.ids, self.wi, seed=1000 + k, offset=self.rank * self.n_local, ctx=self.ctx, ready=False)
             self._out = None
             return
         plan = tab.bucket(self.ids)
@@ -771,15 +772,18 @@ def worker(a):
         algo_bytes = 28 * n_local
         roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP16_MFMA_TFLOPS, "traffic": traffic,
-                "traffic_source": dict(pmc_prov, how="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/profile.sh), "
-                                                     "condensed by tools/summarize_profile.py; looked up, not re-measured in this run"),
+                "traffic_source": dict(pmc_prov, ref=f"{pmc_prov.get('file')}@{(pmc_prov.get('kernel_source_sha256') or 'unknown')[:12]}",
+                                       measured_in_this_run=False,
+                                       how="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (tools/profile.sh), "
+                                           "condensed by tools/summarize_profile.py; looked up, not re-measured in this run"),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "traffic_over_algorithmic": (traffic / algo_bytes) if traffic else None,
                 "traffic_note": ("--context on: a sample launch also WRITES and a pdf launch also READS the per-query context (144 B/query "
                                  "for the 32-wide nets, 5.1x the 28 algorithmic bytes; profiles/r04_ab/: 166 MB per launch); the committed "
                                  "PMC passes are those of the default command and are withheld here") if ctx_on else
                                 "wi / wo / pdf rows read and written once (28 B per query); the per-query context is off by default",
-                "kernel": "flow_kernel", "launches": n_launch, "avg_launch_ms": avg_ms, "shader_clock_mhz": kern_mhz,
+                "kernel": ("flow_kernel32 (csrc/flow32.hip, 32-query tiles)" if getattr(getattr(wl, "smp", None), "tile", 16) == 32
+                           else "flow_kernel (csrc/bsdfd.hip, 16-query tiles)"), "launches": n_launch, "avg_launch_ms": avg_ms, "shader_clock_mhz": kern_mhz,
                 "algorithmic_flop_per_launch": flops_launch, "queries_per_launch": n_local,
                 "kernel_Msamples_per_s": wl.query_launches_per_pass * R * a.steps / (kern_ms * 1e-3) / 1e6,
                 "kernel_Msamples_basis": "queries x flow-kernel launches each goes through (sample and pdf count separately) "
@@ -836,7 +840,8 @@ def worker(a):
                 probe_mhz = _lib.shader_clock_mhz()
                 mhz = kern_mhz or probe_mhz
                 n_simd = torch.cuda.get_device_properties(dev_index).multi_processor_count * 4
-                tiles = n_local / 16
+                tile_q = wl.smp.tile
+                tiles = n_local / tile_q
                 meas = avg_ms * 1e-3 * mhz * 1e6 * n_simd / (tiles * wl.T)
                 # loop-only: the same sample launch at T and 2T (outside the timed region) — the per-query prologue cancels
                 loop = {}
@@ -856,7 +861,7 @@ def worker(a):
                 c_short = loop[wl.T][0] * (loop[wl.T][1] or mhz)
                 loop_mhz = loop[2 * wl.T][1] or mhz
                 meas_loop = (c_long - c_short) / wl.T * 1e-3 * 1e6 * n_simd / tiles
-                ib = {"shader_clock_mhz": mhz, "simds": n_simd,
+                ib = {"shader_clock_mhz": mhz, "simds": n_simd, "tile_queries": tile_q,
                       "shader_clock_basis": "the judged launches' own shader-cycle / wall-clock counters, every wave "
                                             "(bsdfd_profile_clock_mhz); `probe_clock_mhz` is the stand-alone probe kernel (csrc/clock.hip), "
                                             "a similar instruction mix but not the kernel itself",
@@ -868,11 +873,14 @@ def worker(a):
                       "note": "measured_simd_cycles = avg launch time x clock x SIMDs / (tiles x T) carries the per-query prologue's "
                               "share; measured_loop_cycles is the Euler step alone and is what the model describes.  Model = sum over "
                               "the loop's instructions of what each costs the SIMD (tools/isa_mix.py on the shipped build): in this "
-                              "VALU-heavy mix MFMA time and VALU time add — a 16x16x32 MFMA 16.4 cycles, a transcendental ~11 between "
-                              "plain VALU (tools/ubench/RESULTS.md rounds 3-4) — model/measured_loop ~ 1 means the step runs at the "
-                              "hardware's issue rate for this instruction mix"}
+                              "VALU-heavy mix MFMA time and VALU time add — a 16x16x32 MFMA 16.4 cycles, a 32x32x16 32.1, a transcendental "
+                              "~11 between plain VALU (tools/ubench/RESULTS.md rounds 3-4) — model/measured_loop ~ 1 means the step runs "
+                              "at the hardware's issue rate for this instruction mix.  A tile is `tile_queries` queries (one wave64)."}
                 mdl, mdl_prov = isa_model(a.workload)
                 ib["model_source"] = mdl_prov
+                if mdl and mdl.get("tile_queries", 16) != tile_q:
+                    ib["model_source"] = dict(mdl_prov, status=f"model is of the {mdl.get('tile_queries', 16)}-query-tile kernel, the run used {tile_q}")
+                    mdl = None
                 if mdl:
                     ib.update({"model_issue_cycles_per_tile_step": mdl["issue_cycles_total"], "model_mfma_cycles": mdl["issue_cycles_mfma"],
                                "model_valu_cycles": mdl["issue_cycles_valu"], "n_mfma": mdl["n_mfma"], "n_valu": mdl["n_valu"],

@@ -1951,6 +1951,10 @@ int bsdfd_set_profiling(bsdfd_handle h, int32_t enable) {
     h->last_ms = -1.0f;
     for (int i = 0; i < 4; ++i) { h->n_op[i] = 0; h->ms_op[i] = 0.0; }
     HIP_TRY(hipMemset(h->d_clk, 0, (size_t)CLK_SLOTS * 8 * sizeof(unsigned long long)));  // (every pending launch was harvested above: nothing is in flight)
+    // the memset runs on the legacy stream and is asynchronous to the host: a profiled launch issued right behind this call on a
+    // NON-BLOCKING stream (torch side streams, the WavefrontPipeline streams) is not ordered behind it and its counters could be
+    // wiped — wait for it here (this entry point synchronises anyway: see include/bsdfd.h)
+    HIP_TRY(hipStreamSynchronize(nullptr));
     return BSDFD_OK;
 }
 

@@ -50,6 +50,9 @@ constexpr int FR32 = 64 * 16;  // bytes of one A fragment (32 rows x 16 K-values
 #ifndef BSDFD_T32_CACC_LDS
 #define BSDFD_T32_CACC_LDS 2     // the per-query conditioning term in a per-wave LDS slab instead of 16 VGPRs: 0 never, 1 always,
 #endif                           // 2 = the spherical and the fused kernels (they spill at 3 waves/SIMD otherwise; the disk single-op kernel fits)
+#ifndef BSDFD_T32_BASE_SPLIT
+#define BSDFD_T32_BASE_SPLIT 0   // 1: first layer of the base net as 4 split-fp16 MFMAs (all products of the two-way splits) instead of 7 exact-fp32 ones
+#endif
 #ifndef BSDFD_T32_FUSED_SPH_WAVES
 #define BSDFD_T32_FUSED_SPH_WAVES 2   // the fused spherical sample+pdf kernel keeps more state across its two Euler loops
 #endif
@@ -75,7 +78,8 @@ struct L32 {
     static constexpr int BB1 = BW1 + 7 * 256;                      // 2 halves x 8 floats
     static constexpr int BW2 = BB1 + 64;                           // 2 halves x 8 units x 4 outputs
     static constexpr int BB2 = BW2 + 256;                          // 4 floats
-    static constexpr int TOTAL = BB2 + 16;
+    static constexpr int BW1S = BB2 + 16;                          // base net layer 1 as fp16 A fragments (hi, lo): BSDFD_T32_BASE_SPLIT
+    static constexpr int TOTAL = BW1S + 2 * FR32;
 };
 
 __host__ __device__ constexpr int unit32(int v, int h) { return 8 * (v >> 2) + 4 * h + (v & 3); }
@@ -376,8 +380,18 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
                 const f32x4 b0 = Lbb1[0], b1 = Lbb1[1];
                 f32x16 bz = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 const float be[7] = {yh, e[0], e[1], e[2], e[3], e[4], e[5]};
+                if (BSDFD_T32_BASE_SPLIT) {
+                    const float b03[4] = {be[0], be[1], be[2], be[3]}, b47[4] = {be[4], be[5], be[6], 0.0f};
+                    Frag xh, xl;
+                    split_pack<true>(b03, xh.p[0], xh.p[1], xl.p[0], xl.p[1]);
+                    split_pack<true>(b47, xh.p[2], xh.p[3], xl.p[2], xl.p[3]);
+                    const f16x8* Ls = reinterpret_cast<const f16x8*>(smem + LY::BW1S) + lane;
+                    const f16x8 ah = Ls[0], al = Ls[64];
+                    bz = mfma32(ah, xh.v, bz); bz = mfma32(ah, xl.v, bz); bz = mfma32(al, xh.v, bz); bz = mfma32(al, xl.v, bz);
+                } else {
 #pragma unroll
-                for (int j = 0; j < 7; ++j) bz = mfma32f(Lbw1[j * 64 + lane], be[j], bz);
+                    for (int j = 0; j < 7; ++j) bz = mfma32f(Lbw1[j * 64 + lane], be[j], bz);
+                }
                 // (the wait states behind the last MFMA are spelled out: see the note at the base net in bsdfd.hip)
                 asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(bz));
                 const f32x4* Lbw2 = reinterpret_cast<const f32x4*>(smem + LY::BW2 + h * 128);
@@ -762,6 +776,14 @@ std::vector<char> build_image32_t(const bsdfd_desc& d) {
             const int hh = l >> 5, row = l & 31;
             const int col = j == 0 ? hh : 2 + 4 * ((j - 1) >> 1) + 2 * ((j - 1) & 1) + hh;
             F(LY::BW1)[(size_t)j * 64 + l] = row < BASE_HIDDEN ? d.base_w1[(size_t)row * BIN + col] : 0.0f;
+        }
+    for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+            const int hh = l >> 5, row = l & 31;
+            const int col = j == 0 ? hh : 2 + 4 * ((j - 1) >> 1) + 2 * ((j - 1) & 1) + hh;
+            const float w = (j < 7 && row < BASE_HIDDEN) ? d.base_w1[(size_t)row * BIN + col] : 0.0f;
+            H(LY::BW1S)[(size_t)l * 8 + j] = f16_bits(w);
+            H(LY::BW1S)[(size_t)(64 + l) * 8 + j] = f16_bits(w - f16_rnd(w));
         }
     for (int hh = 0; hh < 2; ++hh)
         for (int v = 0; v < 8; ++v) {

@@ -411,16 +411,25 @@ class WavefrontPipeline:
         self.k = 0
 
     def push(self, material_id: torch.Tensor, wi: torch.Tensor, seed: int = 0, offset: int = 0,
-             ctx: Optional[dict] = None, extra_bins: int = 0) -> _Wavefront:
-        """``material_id`` / ``wi`` must be complete when this is called (they are read on a side stream that does not wait
-        for the calling stream — waiting would serialise it behind the previous wavefront's flow kernels)."""
+             ctx: Optional[dict] = None, extra_bins: int = 0, ready=None) -> _Wavefront:
+        """``material_id`` / ``wi`` are read on a side stream.  ``ready`` orders that stream behind their producer:
+
+        * ``None`` (default, always safe): an event recorded NOW on the calling stream — whatever the caller enqueued there to
+          produce the inputs is waited for.  It is also ordered behind the previous wavefronts' flow kernels on that stream,
+          so a caller that produces its inputs on the calling stream gets no overlap of the bucketing with them;
+        * a ``torch.cuda.Event`` the producer recorded right behind its last write (e.g. on its own stream): full overlap;
+        * ``False``: the inputs are complete already (resident arrays, a host-synchronised producer): no wait at all."""
         tab, dev = self.tab, wi.device
         main = torch.cuda.current_stream(dev)
         if self.pre is None or self.pre.device != dev:
             self.pre, self.post = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         w = self.slots[self.k % 2]
         self.k += 1
+        if ready is None:
+            ready = main.record_event()
         with torch.cuda.stream(self.pre):
+            if ready is not False:
+                self.pre.wait_event(ready)
             if w.flow_done is not None:
                 self.pre.wait_event(w.flow_done)       # the flow kernels of wavefront k-2 have read the buffers reused here
             plan = tab.bucket(material_id, extra_bins)  # (the host waits for the counts on THIS stream only)

@@ -135,8 +135,17 @@ def test_wavefront_pipeline_equals_the_serial_stages():
         extra = 1 if k == 3 else 0
         ids = torch.randint(0, len(tab) + extra, (n,), generator=torch.Generator().manual_seed(100 + k)).to(dev)
         wi_k = wi.roll(k, 0).contiguous()
-        torch.cuda.synchronize()                       # (the pipeline reads its inputs on a side stream: they must be complete)
-        w = pipe.push(ids, wi_k, seed=40 + k, offset=7 * k, ctx=ctx_p, extra_bins=extra)
+        # the pipeline reads its inputs on a side stream and orders that stream behind their producer itself: by
+        # default behind everything enqueued on the calling stream so far — NO host synchronisation here, the roll / copy above
+        # is still in flight; with an explicit event of the producer; ready=False only for inputs that are complete (k == 4)
+        if k == 2:
+            ev = torch.cuda.current_stream().record_event()
+            w = pipe.push(ids, wi_k, seed=40 + k, offset=7 * k, ctx=ctx_p, extra_bins=extra, ready=ev)
+        elif k == 4:
+            torch.cuda.synchronize()
+            w = pipe.push(ids, wi_k, seed=40 + k, offset=7 * k, ctx=ctx_p, extra_bins=extra, ready=False)
+        else:
+            w = pipe.push(ids, wi_k, seed=40 + k, offset=7 * k, ctx=ctx_p, extra_bins=extra)
         # the same wavefront, stage by stage
         plan = tab.bucket(ids, extra)
         wi_b = tab.gather(plan, wi_k)

@@ -79,6 +79,17 @@ def _record(name, **kv):
     print(name, {k: (f"{v:.2e}" if isinstance(v, (float, np.floating)) else v) for k, v in kv.items()})
 
 
+def _tail_bound(name, r, r32):
+    """The p99 bounds above say nothing about the last 1 % of the rows: a defect confined to few rows (one lane of a cross-lane
+    reduction on a partial tile, a rarely taken branch) would pass them.  Tail bound: the MAXIMUM relative error
+    over the resolved rows is at most max(2e-3, 4 x the maximum of an fp32-arithmetic evaluation of the reference on the same
+    rows) — near-singular steps lose digits in any fp32 evaluation, a wrong determinant is off by O(1).  The achieved figures
+    are recorded (profiles/r0N_plugin_parity.json)."""
+    bound = max(2e-3, 4.0 * float(r32.max()))
+    _record(name, max=float(r.max()), fp32_reference_max=float(r32.max()), tail_bound=bound, p99=float(np.percentile(r, 99)))
+    assert r.max() <= bound, (name, float(r.max()), bound)
+
+
 @pytest.mark.parametrize("precision", ["f32", "split3"])
 @pytest.mark.parametrize("stem", GOLDEN_CASES)
 def test_network_sampling_vs_oracle_and_golden(stem, precision):
@@ -99,6 +110,8 @@ def test_network_sampling_vs_oracle_and_golden(stem, precision):
     assert np.abs(x - g[f"sample_x_T{T}"]).max() < 1e-4
     rg = _rel(p, g[f"sample_pdf_T{T}"])[ok]
     assert np.percentile(rg, 99) < 2e-4
+    # tail: against the reference's own fp32 run on the same rows (the golden IS that run)
+    _tail_bound(f"network_sampling[{stem}:{precision}]", r, _rel(g[f"sample_pdf_T{T}"].astype(np.float64), po)[ok])
 
 
 @pytest.mark.parametrize("precision", ["f32", "split3"])
@@ -122,6 +135,7 @@ def test_network_pdf_vs_oracle_and_golden(stem, precision):
             assert np.array_equal(np.sign(p[ok]), np.sign(po[ok]))
             rg = _rel(p, g[key])[ok]
             assert np.percentile(rg, 99) < 1e-3
+            _tail_bound(f"network_pdf[{stem}:{precision}:{which}:T{T}]", r, _rel(g[key].astype(np.float64), po)[ok])
 
 @pytest.mark.parametrize("T", [1, 2, 3, 5, 6, 7, 12, 33])
 @pytest.mark.parametrize("stem", ["chm_orange_rgb_disk", "aniso_miro_7_rgb_spherical"])
@@ -792,6 +806,15 @@ def test_plugin_level_vs_reference_plugin_goldens(stem):
     assert np.percentile(err_wo, 99) <= 1e-5
     assert err_wo.max() <= 1e-4
     assert np.percentile(err_pdf, 99) <= 1e-4
+    _tail_bound(f"plugin_sample_tail[{stem}]", err_pdf, noise_pdf)
+    # ... and against the reference's OWN fp32 outputs (north_star: "match the reference path"): at most the two distances from
+    # the fp64 run added up (triangle inequality on the percentiles, 25 % slack: percentiles are not norms).  On chm_orange
+    # spherical this distance is ABOVE 1e-4 by design — the reference's fp32 acos(z / (r + 1e-8)) loses 6.5e-5 rad near the pole
+    # (rendering/brdf_measured_spherical.py:35-39) and the kernel evaluates the same angle well-conditioned
+    vs_ref32 = _rel(pdf, p["sample_pdf_sa"].astype(np.float64))[ok & (p["sample_pdf_sa"] != 0)]
+    _record(f"plugin_sample_vs_ref32[{stem}]", vs_ref32_p99=np.percentile(vs_ref32, 99), kernel_vs_fp64_p99=np.percentile(err_pdf, 99),
+            ref32_vs_fp64_p99=np.percentile(noise_pdf, 99))
+    assert np.percentile(vs_ref32, 99) <= 1.25 * (np.percentile(err_pdf, 99) + np.percentile(noise_pdf, 99))
     # guards: rows the reference zeroes are zero here (rows that sit within fp32 noise of a threshold excepted)
     z_ref, z_got = p["sample_pdf_sa"] == 0, pdf == 0
     decided = (ref_pdf == 0) | (np.abs(ref_pdf) > 1e-30)   # (a density that underflows fp32 may be 0 or a subnormal on either side)
@@ -810,9 +833,12 @@ def test_plugin_level_vs_reference_plugin_goldens(stem):
             want = O.plugin_pdf_spherical(orc, wi3.astype(np.float64), wo3.astype(np.float64), T=T, full_sphere=full)
         okp = np.abs(want) > 1e-6 * np.percentile(np.abs(want), 99)
         e, n32 = _rel(got, want)[okp], _rel(p[key].astype(np.float64), want)[okp]
+        vs32 = _rel(got, p[key].astype(np.float64))[okp & (p[key] != 0)]
         _record(f"plugin_pdf[{stem}:{key}]", pdf_median=np.median(e), pdf_p99=np.percentile(e, 99), ref32_pdf_p99=np.percentile(n32, 99),
-                vs_ref32_p99=np.percentile(_rel(got, p[key].astype(np.float64))[okp], 99))
+                vs_ref32_p99=np.percentile(vs32, 99))
         assert np.percentile(e, 99) <= 1e-4
+        _tail_bound(f"plugin_pdf_tail[{stem}:{key}]", e, n32)
+        assert np.percentile(vs32, 99) <= 1.25 * (np.percentile(e, 99) + np.percentile(n32, 99))   # vs the reference's own fp32 run
         assert (((p[key] == 0) != (got == 0)) & ((want == 0) | (np.abs(want) > 1e-30))).sum() <= 2
     if not full:
         got = s.plugin_pdf(_t(p["pdf_wi3"]), _t(p["pdf_wo3"]), T=T, variant=variant).cpu().numpy()
