@@ -317,6 +317,9 @@ class SingleMaterial:
         assert torch.isfinite(w).all() and torch.isfinite(p).all()
         assert torch.allclose((w * w).sum(1), torch.ones_like(w[:, 0]), atol=1e-4)
 
+    def loop_probe(self, T):
+        self.smp.plugin_sample(self.wi, None, T=T, variant=self.variant, seed=77, out=(self.wo[0], self.pdf_s[0]))
+
     def config(self):
         return {"material": self.material, "domain": self.domain, "euler_steps": self.T, "tile_queries": self.smp.tile,
                 "api": "plugin-level sample()+pdf() (warp + guards fused), in-kernel Philox RNG",
@@ -424,6 +427,9 @@ class Teacher:
 
     def run_pass(self, k):
         self.x = self.smp.flow_samples_only(self.cond, self.x0, T=self.T)
+
+    def loop_probe(self, T):
+        self.smp.flow_samples_only(self.cond, self.x0, T=T)
 
     def result(self):
         return self.x
@@ -563,9 +569,49 @@ def run_secondary(name, device, precision):
            "frac": wl.flops_per_pass * reps / (kern_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS,
            "frac_basis": "algorithmic flop / summed flow-kernel time (HIP events) / 2500 TFLOP/s",
            "precision": wl.precision, "config": wl.config()}
+    if hasattr(wl, "loop_probe"):
+        try:
+            out["issue_bound"] = secondary_issue_bound(name, wl)
+        except Exception as exc:   # a side figure never breaks the line
+            out["issue_bound"] = {"error": repr(exc)}
     del wl
     torch.cuda.empty_cache()
     return out
+
+
+def secondary_issue_bound(name, wl):
+    """Euler-step cost of a secondary workload's kernel in shader cycles per (tile x step) — the same launch at T/2 and at T, each
+    converted at the clock its own launches ran at; the per-query prologue cancels — next to the instruction-issue model of that
+    kernel's loop (tools/isa_mix.py on the shipped build, profiles/isa_mix_latest.json)."""
+    import torch
+    t_hi = wl.T
+    t_lo = max(1, wl.T // 2)
+    cyc = {}
+    for TT in (t_lo, t_hi):
+        for _ in range(2):
+            wl.loop_probe(TT)
+        torch.cuda.synchronize()
+        profiling(wl, True)
+        for _ in range(4):
+            wl.loop_probe(TT)
+        n, ms = profile_read(wl)
+        mhz = profile_clock_mhz(wl)
+        profiling(wl, False)
+        cyc[TT] = (ms / max(n, 1), mhz)
+    n_simd = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count * 4
+    tile_q = wl.smp.tile
+    tiles = wl.n_local / tile_q
+    meas = (cyc[t_hi][0] * cyc[t_hi][1] - cyc[t_lo][0] * cyc[t_lo][1]) / (t_hi - t_lo) * 1e-3 * 1e6 * n_simd / tiles
+    ib = {"tile_queries": tile_q, "measured_loop_cycles_per_tile_step": meas,
+          "loop_basis": f"(launch at T={t_hi} minus at T={t_lo}) / {t_hi - t_lo}: {cyc[t_hi][0]:.4f} ms @ {cyc[t_hi][1]:.0f} MHz, "
+                        f"{cyc[t_lo][0]:.4f} ms @ {cyc[t_lo][1]:.0f} MHz"}
+    mdl, prov = isa_model(name)
+    ib["model_source"] = prov
+    if mdl and mdl.get("tile_queries", 16) == tile_q:
+        ib.update({"model_issue_cycles_per_tile_step": mdl["issue_cycles_total"], "model_mfma_cycles": mdl["issue_cycles_mfma"],
+                   "model_valu_cycles": mdl["issue_cycles_valu"], "n_mfma": mdl["n_mfma"], "n_valu": mdl["n_valu"], "n_trans": mdl.get("n_trans"),
+                   "frac_of_issue_bound": mdl["issue_cycles_total"] / meas})
+    return ib
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -51,7 +51,9 @@ constexpr int FR32 = 64 * 16;  // bytes of one A fragment (32 rows x 16 K-values
 #define BSDFD_T32_CACC_LDS 2     // the per-query conditioning term in a per-wave LDS slab instead of 16 VGPRs: 0 never, 1 always,
 #endif                           // 2 = the spherical and the fused kernels (they spill at 3 waves/SIMD otherwise; the disk single-op kernel fits)
 #ifndef BSDFD_T32_BASE_SPLIT
-#define BSDFD_T32_BASE_SPLIT 0   // 1: first layer of the base net as 4 split-fp16 MFMAs (all products of the two-way splits) instead of 7 exact-fp32 ones
+#define BSDFD_T32_BASE_SPLIT 1   // first layer of the base net as 4 split-fp16 MFMAs (all four products of the two-way splits) instead of 7
+                                 // exact-fp32 ones: -2.5 % kernel time at the plugin's T = 4, worst of the 77 shipped sets 3.9e-5 -> 4.0e-5
+                                 // (sample p99) / 6.3e-5 -> 6.3e-5 (pdf), profiles/r05_ab/ab32_base_net_split*
 #endif
 #ifndef BSDFD_T32_FUSED_SPH_WAVES
 #define BSDFD_T32_FUSED_SPH_WAVES 2   // the fused spherical sample+pdf kernel keeps more state across its two Euler loops

@@ -60,8 +60,10 @@ def test_bench_line_single_gpu_with_secondary_and_cpu_baseline():
     assert 0 < cp["sample_then_pdf"] < cp["no_context"] * 1.02 and 0 < cp["pdf_then_sample"] < cp["no_context"] * 1.02, cp
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["all_cores"]["cores"] >= cb["cores"]
-    ac = cb["all_cores"]  # a child process with a time budget: a figure, or an honest "did not finish" with an upper bound
-    assert (ac["value"] is not None and ac["value"] > 0) or (ac["timed_passes_finished"] == 0 and ac["value_upper_bound"] > 0)
+    ac = cb["all_cores"]  # a child process whose time budget starts AFTER its imports (round 4: 3 x 10 s spent inside `import torch`)
+    assert ac["value"] is not None and ac["value"] > 0, ac
+    assert d["roofline"]["traffic_source"]["measured_in_this_run"] is False and "@" in d["roofline"]["traffic_source"]["ref"]
+    assert ib["tile_queries"] == d["config"]["tile_queries"] == 32     # the judged kernel: csrc/flow32.hip
     for name in ("disk_1Mi_T4", "spherical_16Mi_T8", "mixed_16Mi", "teacher_64x6_4Mi_T128", "complex64_1Mi_T8"):
         s = d["secondary"][name]
         assert "error" not in s, s
