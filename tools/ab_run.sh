@@ -7,7 +7,10 @@ mkdir -p "$ROOT/gpurun_out"; OUTF="$ROOT/gpurun_out/ab_$(date +%H%M%S).jsonl"
 for r in $(seq 1 "$ROUNDS"); do
   for n in "$@"; do
     extra=""; [ "$r" = 1 ] && extra="--acc"
-    BSDFD_LIB_PATH="$ROOT/build_ab/lib_$n.so" timeout 600 python3 "$ROOT/tools/ab.py" --tag "$n" $ARGS $extra | tail -1 >> "$OUTF"
+    # NAME@16 / NAME@32: the same library with the 16- / 32-query-tile kernels selected (BSDFD_TILE)
+    lib="${n%@*}"; tile=""; [ "$lib" != "$n" ] && tile="${n#*@}"
+    ( [ -n "$tile" ] && export BSDFD_TILE="$tile"
+      BSDFD_LIB_PATH="$ROOT/build_ab/lib_$lib.so" timeout 600 python3 "$ROOT/tools/ab.py" --tag "$n" $ARGS $extra | tail -1 >> "$OUTF" )
   done
 done
 python3 "$ROOT/tools/ab_summary.py" "$OUTF"
