@@ -1695,8 +1695,9 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     // The 32-query-tile kernels exist for the reference's two plugin nets in split3 only; everything else runs 16-query tiles.
     int want_tile = d->tile;
     if (want_tile == 0) {
-        const char* ev = std::getenv("BSDFD_TILE");
-        want_tile = ev ? std::atoi(ev) : kDefaultTile;
+        const char* ev = std::getenv("BSDFD_TILE");   // "16" or "32"; anything else (unset, empty, a typo) leaves the default
+        const int et = ev ? std::atoi(ev) : 0;
+        want_tile = (et == 16 || et == 32) ? et : kDefaultTile;
     }
     const bool t32 = want_tile == 32 && bsdfd_tile32_supported(*d, prec);
     for (int m = 0; m < 3; ++m) { h->tile[m] = 16; h->img_of[m] = h->d_img; h->img_bytes[m] = h->lds_bytes[m] = h->L.total; }

@@ -13,15 +13,18 @@
 //     so the lane's accumulator registers 8c .. 8c+7, split hi/lo and packed, ARE the B fragment of chunk c: activations never
 //     leave registers between layers.
 //   * the query's state is DISTRIBUTED over its two lanes: lane h = 0 carries x0 (theta), lane h = 1 carries x1 (phi).  Layer 1
-//     is ONE fp16 MFMA per step: the B slots of a lane are [v_hi, v_lo, v_hi, w_hi, w_lo, w_hi, 0, 0] with (v, w) = (x0, alpha) |
-//     (x1, 0) (disk) or (theta, alpha) | (sin phi, cos phi) (spherical), the A slots [W_hi, W_hi, W_lo] of the matching columns of
-//     W1 (hi hi + hi lo + lo hi inside one instruction), C-in = the per-query conditioning term.
+//     is ONE fp16 MFMA per step: the B slots of a lane are [v_hi, v_lo, v_hi, v_lo, w_hi, w_lo, w_hi, w_lo] with (v, w) = (x0, alpha) |
+//     (x1, 0) (disk) or (theta, alpha) | (sin phi, cos phi) (spherical), the A slots [W_hi, W_hi, W_lo, W_lo] of the matching columns
+//     of W1 (all four products of the two-way splits inside one instruction), C-in = the per-query conditioning term.
 //   * the two-row output layer is an fp32 VALU dot over the lane's 16 units (the last hidden activation is never split) and one
 //     v_permlane32_swap, which leaves v0 in the lower and v1 in the upper half-wave: exactly where x0 and x1 live.
 //   * the Jacobian meets in the middle as in the 16-query kernels (MIM / MIMS); its reduction runs over the 2 lanes of a query
 //     (4 swaps per 32 queries instead of 5 per 16).
 //   * per-tile prologue: lane h encodes dimension h of omega_i (5 sincos), the conditioning term is 6 split-fp16 MFMAs (disk) or
-//     11 exact-fp32 v_mfma_f32_32x32x2_f32 (spherical), the base net's first layer 7 exact-fp32 MFMAs, its second layer VALU.
+//     11 exact-fp32 v_mfma_f32_32x32x2_f32 (spherical), the base net's first layer 4 split-fp16 MFMAs (all four products), its
+//     second layer fp32 VALU.
+//   * 3 waves per SIMD (2 for the fused spherical kernel); no kernel uses scratch: the lane number is re-derived per tile and the
+//     query's row after the Euler loop instead of being carried across it.
 // Same operators, same plugin variants, same context / rng_index / segmented-launch semantics as the 16-query kernels; the base
 // draws are bit-identical to theirs (same Philox counters, same arithmetic).
 #include <hip/hip_runtime.h>
@@ -208,7 +211,7 @@ __device__ __forceinline__ float von_mises_sample32(float mu, float kappa, unsig
 // ---------------------------------------------------------------------------------------------
 // The kernel.  DOMAIN: BSDFD_DOMAIN_*; JAC: track the Jacobian determinant (false: bsdfd_flow_samples_only — the same trajectory
 // as the sampling kernel, bit for bit); FUSED: the two-phase OP_SAMPLE_PDF loop (its own instantiation).
-// 2 waves per SIMD (256 VGPRs): per lane the step keeps 16-register vectors where the 16-query kernels keep 8.
+// Per lane the step keeps 16-register vectors where the 16-query kernels keep 8; BSDFD_T32_WAVES = 3 waves per SIMD (168 VGPRs).
 // ---------------------------------------------------------------------------------------------
 template <int DOMAIN, bool JAC, bool FUSED>
 __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? BSDFD_T32_FUSED_SPH_WAVES : BSDFD_T32_WAVES) void flow_kernel32(const KParams p) {

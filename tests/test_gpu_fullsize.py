@@ -261,6 +261,41 @@ def test_mixed_domains_and_more_than_64_buckets():
         assert torch.equal(t.pdf(idt, wi, wl, ctx=cx), t.pdf(idt, wi, wl))
 
 
+@pytest.mark.parametrize("tile", [16, 32])
+def test_buckets_smaller_than_a_tile(tile, monkeypatch):
+    """Segmented launches whose buckets are smaller than one wave tile (1 .. 40 queries per material, some empty): every
+    bucket starts its own partial tile with its own weight image; results equal the per-material calls bit for bit, for
+    sample, pdf, the fused sample+pdf call and with a per-query context, in both tilings."""
+    monkeypatch.setenv("BSDFD_TILE", str(tile))
+    from bsdf_diffusion_sampling_amd.materials import MaterialTable
+    stems = ["chm_orange_rgb_disk", "aniso_miro_7_rgb_disk", "vch_silk_blue_rgb_disk", "chm_orange_rgb_spherical",
+             "aniso_miro_7_rgb_spherical", "bsdf_3_spherical", "bsdf_7_spherical"]
+    tab = MaterialTable(stems)
+    assert all(s.tile == tile for s in tab.samplers)
+    for n, seed in ((7, 1), (70, 2), (131, 3)):
+        wi, wl = _wi("spherical", n, 40 + seed), _wi("spherical", n, 50 + seed)
+        ids = torch.randint(0, len(stems), (n,), generator=torch.Generator().manual_seed(seed)).to(_dev())
+        ids[ids == 2] = 3                       # an empty bucket in the middle
+        a = tab.sample(ids, wi, seed=5, offset=3)
+        b = tab.sample(ids, wi, seed=5, offset=3, segmented=False)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.isfinite(a[1]).all()
+        pa = tab.pdf(ids, wi, wl)
+        assert torch.equal(pa, tab.pdf(ids, wi, wl, segmented=False))
+        for m in range(len(stems)):
+            sel = (ids == m).nonzero()[:, 0]
+            if len(sel):
+                T = 4 if stems[m].endswith("_disk") else 8
+                variant = 1 if stems[m].startswith("bsdf_") else 0
+                assert torch.equal(pa[sel], tab.samplers[m].plugin_pdf(wi[sel].contiguous(), wl[sel].contiguous(), T=T, variant=variant))
+        cx = {}
+        wo_c, pdf_c = tab.sample(ids, wi, seed=5, offset=3, ctx=cx)
+        assert torch.equal(wo_c, a[0]) and torch.equal(pdf_c, a[1])
+        assert torch.equal(tab.pdf(ids, wi, wl, ctx=cx), pa)
+        wo_f, po_f, pl_f = tab.sample_pdf(ids, wi, wl, seed=5, offset=3)
+        from conftest import same_density
+        assert torch.allclose(wo_f, a[0], atol=2e-5) and same_density(po_f, a[1]) and same_density(pl_f, pa)
+
+
 def test_all_shipped_weight_sets_run_and_are_sane():
     """Every shipped (material, domain) handle builds and samples (config 4's 52 measured sets + 25 bsdf)."""
     from bsdf_diffusion_sampling_amd import _lib, weights as W

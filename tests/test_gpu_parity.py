@@ -188,7 +188,7 @@ def test_flow_samples_only_matches_sampling_path(stem):
         assert torch.allclose(x, xs, atol=1e-6, rtol=0)
 
 
-@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 63, 64, 65, 1000, 4097])
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 1000, 4097])
 def test_ragged_sizes(n):
     g, fw = load_case("chm_orange_rgb_disk")
     s = _sampler(fw, "split3")

@@ -16,8 +16,8 @@ wait
 while [ $# -gt 0 ]; do
   name="$1"; flags="$2"; shift 2
   ( d="$OUT/tmp_$name"; rm -rf "$d"; mkdir -p "$d"; cd "$d"
-    hipcc $COMMON $flags -save-temps=obj -c "$CS/flow32.hip" -o "$d/flow32.o" 2> "$d/err.txt" || { echo "FAILED $name"; grep -m5 error "$d/err.txt"; exit 1; }
-    cp "$d"/flow32-hip-amdgcn-amd-amdhsa-gfx950.s "$OUT/flow32_$name.s"; cp "$d/flow32.o" "$OUT/flow32_$name.o"
+    hipcc $COMMON $flags -save-temps=obj -c "${FLOW32_SRC:-$CS/flow32.hip}" -o "$d/flow32.o" 2> "$d/err.txt" || { echo "FAILED $name"; grep -m5 error "$d/err.txt"; exit 1; }
+    cp "$d"/*-hip-amdgcn-amd-amdhsa-gfx950.s "$OUT/flow32_$name.s"; cp "$d/flow32.o" "$OUT/flow32_$name.o"
     hipcc --offload-arch=gfx950 -shared -fPIC "$OUT/bsdfd.o" "$OUT/flow32_$name.o" "$OUT/wavefront.o" "$OUT/encoding.o" "$OUT/measured.o" "$OUT/bucket.o" "$OUT/clock.o" -o "$OUT/lib_$name.so" && \
     echo "built $name ($flags): $(grep -A14 'name:.*flow_kernel32' $OUT/flow32_$name.s | grep -E 'vgpr_count|private_segment_fixed' | tr -s ' ' | tr '\n' ' ')"
     rm -rf "$d" ) &
