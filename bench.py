@@ -439,7 +439,8 @@ class Teacher:
         assert torch.isfinite(self.x).all()
 
     def config(self):
-        return {"net": "64 x 6 (brdf_diffusion_network_complex)", "euler_steps": self.T, "api": "bsdfd_flow_samples_only, fp16, no Jacobian"}
+        return {"net": "64 x 6 (brdf_diffusion_network_complex)", "euler_steps": self.T, "api": "bsdfd_flow_samples_only, fp16, no Jacobian",
+                "tile_queries": self.smp.tile_samples_only}
 
 
 def make_workload(name, device, rank, precision):
@@ -599,7 +600,7 @@ def secondary_issue_bound(name, wl):
         profiling(wl, False)
         cyc[TT] = (ms / max(n, 1), mhz)
     n_simd = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count * 4
-    tile_q = wl.smp.tile
+    tile_q = wl.smp.tile_samples_only if isinstance(wl, Teacher) else wl.smp.tile
     tiles = wl.n_local / tile_q
     meas = (cyc[t_hi][0] * cyc[t_hi][1] - cyc[t_lo][0] * cyc[t_lo][1]) / (t_hi - t_lo) * 1e-3 * 1e6 * n_simd / tiles
     ib = {"tile_queries": tile_q, "measured_loop_cycles_per_tile_step": meas,

@@ -278,6 +278,7 @@ def expected_flow_kernels(variant: str = "async") -> Dict[str, Dict[str, int]]:
     for dom in (0, 1):                                    # csrc/flow32.hip: <DOMAIN, JAC, FUSED>, compiler-managed LDS reads
         for jac, fused in ((0, 0), (1, 0), (1, 1)):
             out[f"flow_kernel32ILi{dom}ELb{jac}ELb{fused}EE"] = {"async": 0, "waits": 0}
+    out["flow_kernel32wE"] = {"async": 0, "waits": 0}        # the 64 x 6 fp16 teacher on 32-query tiles
     return out
 
 

@@ -315,7 +315,7 @@ def lib():
     L.bsdfd_destroy.argtypes = [vp]
     L.bsdfd_destroy.restype = None
     L.bsdfd_get_info.argtypes = [vp] + [C.POINTER(i32)] * 4
-    L.bsdfd_get_tile.argtypes = [vp, C.POINTER(i32)]
+    L.bsdfd_get_tile.argtypes = [vp, i32, C.POINTER(i32)]
     L.bsdfd_flops_per_query.argtypes = [vp, i32]
     L.bsdfd_flops_per_query.restype = i64
     L.bsdfd_network_sampling.argtypes = [vp, fp, fp, u64, u64, i64, i32, fp, fp, vp]

@@ -1187,6 +1187,7 @@ struct bsdfd_ctx {
     const char* img_of[3];
     int img_bytes[3];
     int lds_bytes[3];   // dynamic LDS of mode m's kernel (>= img_bytes[m])
+    int threads[3];     // workgroup size of mode m's kernel
     // profiling: a ring of HIP event pairs recorded on the launch stream around every launch.  Everything
     // above this line is immutable after create; the profiling state below is guarded by `prof_mu`, so the
     // handle stays re-entrant across host threads / streams with profiling on (launches that are being timed
@@ -1523,13 +1524,12 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     kp.ctx_out = ctx.out; kp.ctx_in = ctx.in; kp.seg_base = ctx.seg_base; kp.rng_index = ctx.rng_index;
     kp.clk = nullptr;
 
-    const int NM = h->width / 16;
-    const int threads = threads_for(NM);
+    const int mode = op == OP_SAMPLES_ONLY ? 0 : (op == OP_SAMPLE_PDF ? 2 : 1);
+    const int threads = h->threads[mode];
     const int waves = threads / 64;
     // grid: 4 rounds of the resident capacity (blocks per CU from the occupancy query of the
     // instantiated kernel: VGPR- or LDS-limited); block-granular dynamic balancing measured ~4 %
     // faster than an exactly-resident persistent grid (tools/tscan.py sweep)
-    const int mode = op == OP_SAMPLES_ONLY ? 0 : (op == OP_SAMPLE_PDF ? 2 : 1);
     kp.img = h->img_of[mode];
     kp.L.total = h->img_bytes[mode];
     const int tile = h->tile[mode];
@@ -1700,15 +1700,19 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
         want_tile = (et == 16 || et == 32) ? et : kDefaultTile;
     }
     const bool t32 = want_tile == 32 && bsdfd_tile32_supported(*d, prec);
-    for (int m = 0; m < 3; ++m) { h->tile[m] = 16; h->img_of[m] = h->d_img; h->img_bytes[m] = h->lds_bytes[m] = h->L.total; }
+    for (int m = 0; m < 3; ++m) {
+        h->tile[m] = 16; h->img_of[m] = h->d_img; h->img_bytes[m] = h->lds_bytes[m] = h->L.total;
+        h->threads[m] = threads_for(h->width / 16);
+    }
     if (t32 && e == hipSuccess) {
-        const std::vector<char> img32 = bsdfd_build_image32(*d);
+        const std::vector<char> img32 = bsdfd_build_image32(*d, prec);
         e = hipMalloc(reinterpret_cast<void**>(&h->d_img32), img32.size());
         if (e == hipSuccess) e = hipMemcpy(h->d_img32, img32.data(), img32.size(), hipMemcpyHostToDevice);
         for (int m = 0; m < 3; ++m)
-            if (bsdfd_kernel32(h->domain, m)) {
+            if (bsdfd_kernel32(*d, prec, m)) {
                 h->tile[m] = 32; h->img_of[m] = h->d_img32; h->img_bytes[m] = (int)img32.size();
-                h->lds_bytes[m] = bsdfd_kernel32_lds_bytes(h->domain, m);
+                h->lds_bytes[m] = bsdfd_kernel32_lds_bytes(*d, prec, m);
+                h->threads[m] = bsdfd_kernel32_threads(*d, prec, m);
             }
     }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->d_clk), (size_t)CLK_SLOTS * 8 * sizeof(unsigned long long));
@@ -1718,12 +1722,12 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
         if (e == hipSuccess) e = hipEventCreate(&h->ev1[i]);
     }
     for (int jac = 0; jac < 3 && e == hipSuccess; ++jac) {
-        h->kfun[jac] = h->tile[jac] == 32 ? bsdfd_kernel32(h->domain, jac) : kernel_ptr(h->domain, h->width / 16, h->n_hidden, prec, jac);
+        h->kfun[jac] = h->tile[jac] == 32 ? bsdfd_kernel32(*d, prec, jac) : kernel_ptr(h->domain, h->width / 16, h->n_hidden, prec, jac);
         // dynamic LDS above the default cap needs the attribute (per function and device)
         e = hipFuncSetAttribute(h->kfun[jac], hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_bytes[jac] + (int)lds_pad());
         int nb = 0;
         if (e == hipSuccess)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h->kfun[jac], threads_for(h->width / 16), (size_t)h->lds_bytes[jac] + lds_pad());
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, h->kfun[jac], h->threads[jac], (size_t)h->lds_bytes[jac] + lds_pad());
         h->per_cu[jac] = nb;
     }
     if (e != hipSuccess) {
@@ -1802,9 +1806,10 @@ int bsdfd_get_info(bsdfd_handle h, int32_t* domain, int32_t* width, int32_t* n_h
     return BSDFD_OK;
 }
 
-int bsdfd_get_tile(bsdfd_handle h, int32_t* tile) {
+int bsdfd_get_tile(bsdfd_handle h, int32_t op, int32_t* tile) {
     if (!h || !tile) return fail(BSDFD_EINVAL, "null argument");
-    *tile = h->tile[1];
+    if (op < 0 || op > 3) return fail(BSDFD_EINVAL, "op must be one of BSDFD_OP_SAMPLE, _PDF, _SAMPLES_ONLY, _SAMPLE_PDF");
+    *tile = h->tile[op == OP_SAMPLES_ONLY ? 0 : (op == OP_SAMPLE_PDF ? 2 : 1)];
     return BSDFD_OK;
 }
 

@@ -4,13 +4,15 @@
 
 #include "bsdfd.h"
 
-// true for the two nets the reference's plugins load — disk 25-32x3-2 (rendering/utils/model.py:479-501) and spherical
-// 26-32x4-2 (:422-446) — in precision split3: the shapes the 32-query-tile kernels are instantiated for
+// true where a 32-query-tile kernel exists for SOME mode of this net: the reference's two plugin nets — disk 25-32x3-2
+// (rendering/utils/model.py:479-501) and spherical 26-32x4-2 (:422-446) — in precision split3 (all modes), and the 64 x 6
+// spherical teacher (:449-477) in precision f16 (samples-only mode)
 bool bsdfd_tile32_supported(const bsdfd_desc& d, int prec);
-// the weight image of those kernels (fragment order of v_mfma_f32_32x32x16_f16; compile-time offsets, see L32 in flow32.hip)
-std::vector<char> bsdfd_build_image32(const bsdfd_desc& d);
+// the weight image of those kernels (fragment order of v_mfma_f32_32x32x16_f16; compile-time offsets, see L32 / L32W in flow32.hip)
+std::vector<char> bsdfd_build_image32(const bsdfd_desc& d, int prec);
 // mode 0: no Jacobian (flow_samples_only), 1: Jacobian (network_sampling / network_pdf / plugin sample / plugin pdf), 2: fused
-// sample+pdf; nullptr = no such kernel
-const void* bsdfd_kernel32(int domain, int mode);
-// dynamic LDS of those kernels: the image + per-wave scratch
-int bsdfd_kernel32_lds_bytes(int domain, int mode);
+// sample+pdf; nullptr = no such kernel for this net / precision (the 16-query-tile kernel of csrc/bsdfd.hip serves the mode)
+const void* bsdfd_kernel32(const bsdfd_desc& d, int prec, int mode);
+// dynamic LDS of that kernel (the image + per-wave scratch) and its workgroup size
+int bsdfd_kernel32_lds_bytes(const bsdfd_desc& d, int prec, int mode);
+int bsdfd_kernel32_threads(const bsdfd_desc& d, int prec, int mode);

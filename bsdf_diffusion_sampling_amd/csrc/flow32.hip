@@ -799,18 +799,211 @@ std::vector<char> build_image32_t(const bsdfd_desc& d) {
     return img;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The reflow TEACHER on 32-query tiles: the reference's 64 x 6 spherical net (NN_cond_pos_spherical_complicate,
+// rendering/utils/model.py:449-477), single fp16 product, no Jacobian — bsdfd_flow_samples_only in precision f16, the library's
+// stand-in for the reference's only tiny-cuda-nn call site (learning_repo_cleanup/spherical_domain_sampling.py:147-166).
+// 64 units = two M-tiles of the 32x32 shape: lane (h, n) holds, for query n, units 32 mt + u(v, h) in z[mt][v]; a contraction is
+// 2 M-tiles x 4 K-chunks = 8 MFMAs (chunk c = 2 mt' + c': registers 8 c' .. 8 c' + 7 of z[mt'], rounded to fp16, ARE its B
+// fragment).  Layer 1: one MFMA per M-tile with the state as hi + lo ([v_hi, v_lo, w_hi, w_lo] against [Wv, Wv, Ww, Ww]: the state
+// itself is not rounded to 11 bits, the weights are, as in every other layer of this mode); the conditioning term exact fp32 once
+// per query; the output layer an fp32 VALU dot.  Operator io only (the teacher has no plugin form).
+// ---------------------------------------------------------------------------------------------
+struct L32W {
+    static constexpr int NH = 6;
+    static constexpr int A1 = 0;                              // 2 fragments (M-tile 0, 1)
+    static constexpr int WC = A1 + 2 * FR32;                  // conditioning: 2 M-tiles x 11 x 64 floats
+    static constexpr int WH = WC + 2 * 11 * 256;              // (NH - 1) matrices x 2 M-tiles x 4 K-chunks fragments
+    static constexpr int WOUT = WH + (NH - 1) * 8 * FR32;     // 2 halves x 2 M-tiles x 16 x (Wout[0][u], Wout[1][u]) floats
+    static constexpr int TOTAL = WOUT + 2 * 2 * 128;
+};
+
+// 512 threads per workgroup: 8 waves share one 48-KiB image, 2 workgroups per CU = 4 waves per SIMD (116 VGPRs).
+__global__ __launch_bounds__(512, 4) void flow_kernel32w(const KParams p) {
+    using LY = L32W;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (p.clk) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(p.img);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = threadIdx.x; i < LY::TOTAL / 16; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane0 = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto uniform_f = [](float x) -> float { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); };
+    auto uniform_d = [](double x) -> double {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    const double invT_d = uniform_d(1.0 / (double)p.T);
+    const bool t_pow2 = (p.T & (p.T - 1)) == 0;
+    const float invT = uniform_f((float)invT_d);
+    const long long ntiles = (p.N + 31) / 32;
+    const int cl = p.chunk_log2;
+    const long long chunk = (long long)waves_per_block << cl;
+    for (long long it = 0;; ++it) {
+        const long long chunk_base = ((it >> cl) * gridDim.x + blockIdx.x) * chunk;
+        if (chunk_base >= ntiles) break;
+        const long long tile = chunk_base + (it & ((1 << cl) - 1)) * waves_per_block + wave;
+        if (tile >= ntiles) continue;
+        auto opaque = [](int x) -> int { asm volatile("" : "+v"(x)); return x; };
+        const int lane = opaque(lane0);
+        const int h = lane >> 5, n = lane & 31;
+        const long long qi_raw = tile * 32 + n;
+        const long long qi = qi_raw < p.N ? qi_raw : p.N - 1;
+        const float2 c2 = reinterpret_cast<const float2*>(p.in_a)[qi];
+        const float2 b2 = reinterpret_cast<const float2*>(p.in_b)[qi];
+        const float yh = h ? c2.y : c2.x;
+        float xs = h ? b2.y : b2.x;
+        // conditioning term, exact fp32 (rendering/utils/model.py:26-57 encoding, W1[:, PE] PE(omega_i))
+        f32x16 cacc[2] = {zero16, zero16};
+        {
+            float e[11];
+#pragma unroll
+            for (int b = 0; b < PE_BANDS; ++b) sincos_enc(yh * (float)(1 << b), e[2 * b], e[2 * b + 1]);
+            e[10] = yh;
+            const float* Lwc = reinterpret_cast<const float*>(smem + LY::WC);
+#pragma unroll
+            for (int j = 0; j < 11; ++j) {
+                cacc[0] = mfma32f(Lwc[j * 64 + lane], e[j], cacc[0]);
+                cacc[1] = mfma32f(Lwc[(11 + j) * 64 + lane], e[j], cacc[1]);
+            }
+        }
+        for (int t = 0; t < p.T; ++t) {
+            asm volatile("s_nop 0");   // keeps the weight-fragment loads inside the loop
+            float alpha;
+            if (t_pow2) alpha = (float)t * invT;
+            else alpha = (float)((double)t * invT_d);
+            float sp, cp;
+            sincos_enc(xs, sp, cp);
+            const float vin = h ? sp : xs, win = h ? cp : alpha;
+            const float vh = hi_part(vin), wh = hi_part(win);
+            Frag b1;
+            b1.p[0] = (f16x2){(_Float16)vh, (_Float16)(vin - vh)};
+            b1.p[1] = (f16x2){(_Float16)wh, (_Float16)(win - wh)};
+            b1.p[2] = b1.p[3] = (f16x2){(_Float16)0.0f, (_Float16)0.0f};
+            const f16x8* La1 = reinterpret_cast<const f16x8*>(smem + LY::A1) + lane;
+            f32x16 z[2];
+            z[0] = mfma32(La1[0], b1.v, cacc[0]);
+            z[1] = mfma32(La1[64], b1.v, cacc[1]);
+            float hv[2][16];
+#pragma unroll
+            for (int layer = 0; layer < LY::NH; ++layer) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) hv[mt][v] = z[mt][v] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[mt][v]));
+                if (layer == LY::NH - 1) break;
+                Frag fr[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        fr[c].p[k] = (f16x2){(_Float16)hv[c >> 1][8 * (c & 1) + 2 * k], (_Float16)hv[c >> 1][8 * (c & 1) + 2 * k + 1]};
+                const f16x8* W = reinterpret_cast<const f16x8*>(smem + LY::WH + layer * 8 * FR32) + lane;
+#pragma unroll
+                for (int mo = 0; mo < 2; ++mo) {
+                    f32x16 a = mfma32(W[(mo * 4 + 0) * 64], fr[0].v, zero16);
+                    a = mfma32(W[(mo * 4 + 1) * 64], fr[1].v, a);
+                    a = mfma32(W[(mo * 4 + 2) * 64], fr[2].v, a);
+                    z[mo] = mfma32(W[(mo * 4 + 3) * 64], fr[3].v, a);
+                }
+            }
+            const f32x4* Lwo = reinterpret_cast<const f32x4*>(smem + LY::WOUT + h * 256);
+            f32x2 pv = {0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const f32x4 w = Lwo[mt * 8 + k];
+                    pv = __builtin_elementwise_fma((f32x2){hv[mt][2 * k], hv[mt][2 * k]}, (f32x2){w[0], w[1]}, pv);
+                    pv = __builtin_elementwise_fma((f32x2){hv[mt][2 * k + 1], hv[mt][2 * k + 1]}, (f32x2){w[2], w[3]}, pv);
+                }
+            float pv0 = pv[0], pv1 = pv[1];
+            swap32(pv0, pv1);
+            xs = fmaf(invT, pv0 + pv1, xs);
+        }
+        float x0, x1;
+        both32(xs, x0, x1);
+        const int ne = opaque(n);
+        const long long qe = tile * 32 + ne;
+        if (qe < p.N && (opaque(lane0) >> 5) == 0) reinterpret_cast<float2*>(p.out_x)[qe] = make_float2(x0, x1);
+    }
+    if (p.clk) {
+        const unsigned long long dc = (unsigned long long)__builtin_readcyclecounter() - clk_c0;
+        const unsigned long long dr = (unsigned long long)__builtin_amdgcn_s_memrealtime() - clk_r0;
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long* slot = p.clk + 8 * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (CLK_SLOTS - 1));
+            atomicAdd(slot, dc);
+            atomicAdd(slot + 1, dr);
+        }
+    }
+}
+
+std::vector<char> build_image32w(const bsdfd_desc& d) {
+    using LY = L32W;
+    constexpr int W = 64, NH = LY::NH, SD = 3, IN = SD + 1 + 2 + 4 * PE_BANDS;
+    std::vector<float> w_in((size_t)W * IN), w_out((size_t)2 * W);
+    for (size_t i = 0; i < w_in.size(); ++i) w_in[i] = (float)((double)d.w_in[i] * -1.4426950408889634);
+    for (size_t i = 0; i < w_out.size(); ++i) w_out[i] = (float)((double)d.w_out[i] * -0.6931471805599453);
+    std::vector<char> img(LY::TOTAL, 0);
+    auto F = [&](int o) { return reinterpret_cast<float*>(img.data() + o); };
+    auto H = [&](int o) { return reinterpret_cast<uint16_t*>(img.data() + o); };
+    auto pe_col = [&](int ei, int hh) { return ei < 10 ? SD + 1 + 2 + 4 * (ei >> 1) + 2 * (ei & 1) + hh : SD + 1 + hh; };
+    for (int mt = 0; mt < 2; ++mt)
+        for (int l = 0; l < 64; ++l) {
+            const int hh = l >> 5, row = 32 * mt + (l & 31);
+            const float wv = w_in[(size_t)row * IN + (hh == 0 ? 0 : 1)], ww = w_in[(size_t)row * IN + (hh == 0 ? 3 : 2)];
+            const float sl[8] = {wv, wv, ww, ww, 0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 8; ++j) H(LY::A1)[(size_t)(mt * 64 + l) * 8 + j] = f16_bits(sl[j]);
+            for (int j = 0; j < 11; ++j) F(LY::WC)[(size_t)(mt * 11 + j) * 64 + l] = w_in[(size_t)row * IN + pe_col(j, hh)];
+        }
+    for (int layer = 0; layer < NH - 1; ++layer)
+        for (int mo = 0; mo < 2; ++mo)
+            for (int c = 0; c < 4; ++c)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int hh = l >> 5, row = 32 * mo + (l & 31), k = 32 * (c >> 1) + unit32(8 * (c & 1) + j, hh);
+                        H(LY::WH)[((size_t)(layer * 8 + mo * 4 + c) * 64 + l) * 8 + j] = f16_bits(d.w_hidden[((size_t)layer * W + row) * W + k]);
+                    }
+    for (int hh = 0; hh < 2; ++hh)
+        for (int mt = 0; mt < 2; ++mt)
+            for (int v = 0; v < 16; ++v) {
+                const int u = 32 * mt + unit32(v, hh);
+                F(LY::WOUT)[hh * 64 + mt * 32 + 2 * v] = w_out[u];
+                F(LY::WOUT)[hh * 64 + mt * 32 + 2 * v + 1] = w_out[W + u];
+            }
+    return img;
+}
+
+// which 32-query-tile kernel serves (net, precision, mode): 0 none, 1 flow_kernel32, 2 flow_kernel32w
+int kind32(const bsdfd_desc& d, int prec, int mode) {
+    if (prec == BSDFD_PREC_SPLIT3 && d.width == 32 &&
+        ((d.domain == BSDFD_DOMAIN_DISK && d.n_hidden == 3) || (d.domain == BSDFD_DOMAIN_SPHERICAL && d.n_hidden == 4)))
+        return 1;
+    if (prec == BSDFD_PREC_F16 && d.width == 64 && d.n_hidden == 6 && d.domain == BSDFD_DOMAIN_SPHERICAL && mode == 0) return 2;
+    return 0;
+}
+
 }  // namespace
 
 bool bsdfd_tile32_supported(const bsdfd_desc& d, int prec) {
-    if (prec != BSDFD_PREC_SPLIT3 || d.width != 32) return false;
-    return (d.domain == BSDFD_DOMAIN_DISK && d.n_hidden == 3) || (d.domain == BSDFD_DOMAIN_SPHERICAL && d.n_hidden == 4);
+    return kind32(d, prec, 0) != 0 || kind32(d, prec, 1) != 0;
 }
 
-std::vector<char> bsdfd_build_image32(const bsdfd_desc& d) {
+std::vector<char> bsdfd_build_image32(const bsdfd_desc& d, int prec) {
+    if (kind32(d, prec, 0) == 2) return build_image32w(d);
     return d.domain == BSDFD_DOMAIN_DISK ? build_image32_t<BSDFD_DOMAIN_DISK>(d) : build_image32_t<BSDFD_DOMAIN_SPHERICAL>(d);
 }
 
-int bsdfd_kernel32_lds_bytes(int domain, int mode) {
+int bsdfd_kernel32_lds_bytes(const bsdfd_desc& d, int prec, int mode) {
+    if (kind32(d, prec, mode) == 2) return L32W::TOTAL;
+    const int domain = d.domain;
     if (mode == 2)
         return domain == BSDFD_DOMAIN_DISK ? L32<BSDFD_DOMAIN_DISK>::TOTAL + 4 * CaccLds<BSDFD_DOMAIN_DISK, true>::slab
                                            : L32<BSDFD_DOMAIN_SPHERICAL>::TOTAL + 4 * CaccLds<BSDFD_DOMAIN_SPHERICAL, true>::slab;
@@ -818,8 +1011,13 @@ int bsdfd_kernel32_lds_bytes(int domain, int mode) {
                                        : L32<BSDFD_DOMAIN_SPHERICAL>::TOTAL + 4 * CaccLds<BSDFD_DOMAIN_SPHERICAL, false>::slab;
 }
 
-const void* bsdfd_kernel32(int domain, int mode) {
-    const bool disk = domain == BSDFD_DOMAIN_DISK;
+int bsdfd_kernel32_threads(const bsdfd_desc& d, int prec, int mode) { return kind32(d, prec, mode) == 2 ? 512 : 256; }
+
+const void* bsdfd_kernel32(const bsdfd_desc& d, int prec, int mode) {
+    const int kind = kind32(d, prec, mode);
+    if (kind == 2) return reinterpret_cast<const void*>(flow_kernel32w);
+    if (kind != 1) return nullptr;
+    const bool disk = d.domain == BSDFD_DOMAIN_DISK;
     switch (mode) {
         case 0: return disk ? reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_DISK, false, false>)
                             : reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_SPHERICAL, false, false>);

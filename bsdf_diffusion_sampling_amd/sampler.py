@@ -80,8 +80,10 @@ class FlowSampler:
         p = C.c_int32()
         _lib.check(L.bsdfd_get_info(h, None, None, None, C.byref(p)))
         self.precision = {v: k for k, v in _lib.PRECISIONS.items()}[p.value]
-        _lib.check(L.bsdfd_get_tile(h, C.byref(p)))
-        self.tile = int(p.value)   # queries per wave tile of the kernels in effect (16 | 32)
+        _lib.check(L.bsdfd_get_tile(h, 0, C.byref(p)))
+        self.tile = int(p.value)               # queries per wave tile of the sample / pdf kernels in effect (16 | 32)
+        _lib.check(L.bsdfd_get_tile(h, 2, C.byref(p)))
+        self.tile_samples_only = int(p.value)  # ... and of the kernel behind flow_samples_only
 
     def close(self):
         if getattr(self, "_h", None):

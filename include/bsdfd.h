@@ -52,6 +52,12 @@ extern "C" {
 
 typedef struct bsdfd_ctx* bsdfd_handle;
 
+/* The four kinds of flow-kernel launch (bsdfd_get_tile, bsdfd_profile_read_op). */
+#define BSDFD_OP_SAMPLE 0        /* network_sampling, plugin_sample      */
+#define BSDFD_OP_PDF 1           /* network_pdf, plugin_pdf              */
+#define BSDFD_OP_SAMPLES_ONLY 2  /* flow_samples_only                    */
+#define BSDFD_OP_SAMPLE_PDF 3    /* plugin_sample_pdf                    */
+
 /* Host pointers to fp32 row-major [out, in] matrices exactly as nn.Linear.weight
  * stores them (reference checkpoints: rendering/checkpoints_new/.../brdf_rectify_network*.pth
  * and brdf_pretrain_network*.pth, loaded at rendering/brdf_measured_disk.py:43-51).
@@ -66,7 +72,8 @@ typedef struct bsdfd_desc {
     int32_t precision;      /* BSDFD_PREC_*                                              */
     int32_t tile;           /* queries per wave64 tile of the Jacobian kernels: 0 = library default (overridable with
                              * $BSDFD_TILE), 16 = the 16x16x32-MFMA kernels, 32 = the 32x32x16-MFMA kernels (the reference's two
-                             * plugin nets — disk 32x3, spherical 32x4 — in BSDFD_PREC_SPLIT3; silently 16 for anything else).
+                             * plugin nets — disk 32x3, spherical 32x4 — in BSDFD_PREC_SPLIT3, and bsdfd_flow_samples_only of the
+                             * 64 x 6 spherical teacher in BSDFD_PREC_F16; silently 16 for anything else).
                              * Both tilings implement the same operators to the same tolerance. */
     const float* w_in;      /* [width, state_dim + 1 + 2 + 4*pe_bands], cols [state|alpha|PE(omega_i)] */
     const float* w_hidden;  /* [n_hidden-1, width, width]                                */
@@ -93,9 +100,10 @@ void bsdfd_destroy(bsdfd_handle h);
 int bsdfd_get_info(bsdfd_handle h, int32_t* domain, int32_t* width, int32_t* n_hidden,
                    int32_t* precision);
 int64_t bsdfd_flops_per_query(bsdfd_handle h, int32_t T);
-/* Queries per wave64 tile of the kernels this handle launches (16 or 32, see bsdfd_desc.tile): the granularity of the opaque
- * per-query context below.  No counterpart in the reference. */
-int bsdfd_get_tile(bsdfd_handle h, int32_t* tile);
+/* Queries per wave64 tile (16 or 32, see bsdfd_desc.tile) of the kernel this handle launches for `op` (BSDFD_OP_*).  For
+ * BSDFD_OP_SAMPLE / _PDF it is the granularity of the opaque per-query context below.  (A handle may mix tilings: the 64 x 6 teacher
+ * in BSDFD_PREC_F16 has a 32-query-tile kernel for bsdfd_flow_samples_only alone.)  No counterpart in the reference. */
+int bsdfd_get_tile(bsdfd_handle h, int32_t op, int32_t* tile);
 
 /* network_sampling_disk / network_sampling_spherical
  * (rendering/utils/mlp_brdf_sampling.py:17-51, :106-140).
@@ -218,10 +226,6 @@ float bsdfd_last_kernel_ms(bsdfd_handle h);
 /* The same totals for ONE kind of launch (bench.py's sample / pdf split of the timed region itself): `op` is
  * BSDFD_OP_SAMPLE (network_sampling, plugin_sample), BSDFD_OP_PDF (network_pdf, plugin_pdf), BSDFD_OP_SAMPLES_ONLY
  * (flow_samples_only) or BSDFD_OP_SAMPLE_PDF (plugin_sample_pdf).  No counterpart in the reference. */
-#define BSDFD_OP_SAMPLE 0
-#define BSDFD_OP_PDF 1
-#define BSDFD_OP_SAMPLES_ONLY 2
-#define BSDFD_OP_SAMPLE_PDF 3
 int bsdfd_profile_read_op(bsdfd_handle h, int32_t op, int64_t* n_launches, double* total_ms);
 /* Shader clock (MHz) the chip sustained UNDER THE PROFILED LAUNCHES THEMSELVES: while profiling is enabled every wave adds its
  * lifetime in shader cycles (s_memtime) and in ticks of the constant-rate wall clock (s_memrealtime,

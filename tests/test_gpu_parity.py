@@ -175,7 +175,13 @@ def test_f16_precision_is_tcnn_class(stem):
     xo, po = O.Oracle(fw).network_sampling(g["wi"], g["x0"], T)
     assert np.abs(x.cpu().numpy() - xo).max() < 1e-2
     xs = s.flow_samples_only(_t(g["wi"]), _t(g["x0"]), T=T).cpu().numpy()
-    assert np.array_equal(xs, x.cpu().numpy()) or np.abs(xs - x.cpu().numpy()).max() < 1e-6
+    if s.tile_samples_only == s.tile:
+        # one kernel family behind both calls: the samples-only kernel walks the sampling kernel's trajectory
+        assert np.array_equal(xs, x.cpu().numpy()) or np.abs(xs - x.cpu().numpy()).max() < 1e-6
+    else:
+        # the 64 x 6 teacher: flow_samples_only runs the 32-query-tile kernel (flow_kernel32w), network_sampling the 16-query one —
+        # two fp16-class evaluations (another summation order, state as hi + lo in layer 1): each inside the class's 1e-2
+        assert fw.width == 64 and np.abs(xs - xo).max() < 1e-2 and np.abs(xs - x.cpu().numpy()).max() < 2e-2
 
 
 @pytest.mark.parametrize("stem", ["chm_orange_rgb_disk", "chm_orange_rgb_spherical"])
@@ -490,11 +496,21 @@ def test_reflow_teacher_sampler_T128_fp16_class():
     n, T = 1024, 128
     wi, x0 = g["wi"][:n], g["x0"][:n]
     xo, _ = O.Oracle(fw).flow(x0, wi, T, reverse=False)
-    x16 = _sampler(fw, "f16").flow_samples_only(_t(wi), _t(x0), T=T).cpu().numpy()
+    import os
+    s16 = _sampler(fw, "f16")
+    # the fp16 teacher has a 32-query-tile kernel of its own for this call (csrc/flow32.hip: flow_kernel32w) — the default
+    assert s16.tile_samples_only == (16 if os.environ.get("BSDFD_TILE") == "16" else 32) and s16.tile == 16
+    x16 = s16.flow_samples_only(_t(wi), _t(x0), T=T).cpu().numpy()
     xs3 = _sampler(fw, "split3").flow_samples_only(_t(wi), _t(x0), T=T).cpu().numpy()
     e16 = np.abs(x16 - xo).max(1)
     assert np.percentile(e16, 99) < 2e-2, np.percentile(e16, [50, 99, 100])
     assert np.abs(xs3 - xo).max() < 1e-4, np.abs(xs3 - xo).max()
+    # ragged N / a query count that is not a multiple of the tile: same rows, same values; non-power-of-two T
+    for m in (1, 31, 333):
+        assert np.array_equal(s16.flow_samples_only(_t(wi[:m]), _t(x0[:m]), T=T).cpu().numpy(), x16[:m])
+    xo7, _ = O.Oracle(fw).flow(x0[:256], wi[:256], 7, reverse=False)
+    e7 = np.abs(s16.flow_samples_only(_t(wi[:256]), _t(x0[:256]), T=7).cpu().numpy() - xo7).max(1)
+    assert np.percentile(e7, 99) < 2e-2, np.percentile(e7, [50, 99, 100])
 
 
 @pytest.mark.parametrize("T", [128, 256])

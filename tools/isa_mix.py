@@ -53,7 +53,8 @@ KERNEL_OF_WORKLOAD = {  # bench.py workload -> mangled-name fragment of its flow
     "disk_1Mi_T8": "flow_kernel32ILi0ELb1ELb0E",
     "disk_1Mi_T4": "flow_kernel32ILi0ELb1ELb0E",
     "spherical_16Mi_T8": "flow_kernel32ILi1ELb1ELb0E",
-    "teacher_64x6_4Mi_T128": "flow_kernelILi1ELi4ELi3ELb0ELi6ELb0E",
+    "teacher_64x6_4Mi_T128": "flow_kernel32wE",
+    "teacher_64x6_4Mi_T128@tile16": "flow_kernelILi1ELi4ELi3ELb0ELi6ELb0E",
     "complex64_1Mi_T8": "flow_kernelILi1ELi4ELi2ELb1ELi6ELb0E",
     # the 16-query-tile kernels of the same nets (bsdfd_desc.tile = 16), for comparison
     "disk_1Mi_T8@tile16": "flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E",
@@ -168,7 +169,8 @@ def main():
                                     ("spherical 32x4 fused sample+pdf, 32-query tiles", "flow_kernel32ILi1ELb1ELb1E", 2),
                                     ("disk 32x3 split3, 16-query tiles", "flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E", 3),
                                     ("spherical 32x4 split3, 16-query tiles", "flow_kernelILi1ELi2ELi2ELb1ELi4ELb0E", 3),
-                                    ("teacher 64x6 f16, no Jacobian", "flow_kernelILi1ELi4ELi3ELb0ELi6ELb0E", 4),
+                                    ("teacher 64x6 f16, no Jacobian, 32-query tiles", "flow_kernel32wE", 4),
+                                    ("teacher 64x6 f16, no Jacobian, 16-query tiles", "flow_kernelILi1ELi4ELi3ELb0ELi6ELb0E", 4),
                                     ("64x6 split3 with Jacobian (complex64_1Mi_T8)", "flow_kernelILi1ELi4ELi2ELb1ELi6ELb0E", 2)):
                 v = kernel_meta(lines, key).get("vgpr_count", 0)
                 waves = 8 if v <= 64 else 512 // ((v + 7) // 8 * 8)
