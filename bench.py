@@ -581,19 +581,19 @@ def run_secondary(name, device, precision):
 
 
 def secondary_issue_bound(name, wl):
-    """Euler-step cost of a secondary workload's kernel in shader cycles per (tile x step) — the same launch at T/2 and at T, each
+    """Euler-step cost of a secondary workload's kernel in shader cycles per (tile x step) — the same launch at T and at 2T, each
     converted at the clock its own launches ran at; the per-query prologue cancels — next to the instruction-issue model of that
     kernel's loop (tools/isa_mix.py on the shipped build, profiles/isa_mix_latest.json)."""
     import torch
-    t_hi = wl.T
-    t_lo = max(1, wl.T // 2)
+    # (T, 2T) as for the judged workload; the 128-step teacher (44 ms per launch) uses (T/2, T)
+    t_lo, t_hi = (wl.T // 2, wl.T) if wl.T >= 64 else (wl.T, 2 * wl.T)
     cyc = {}
     for TT in (t_lo, t_hi):
-        for _ in range(2):
+        for _ in range(3):
             wl.loop_probe(TT)
         torch.cuda.synchronize()
         profiling(wl, True)
-        for _ in range(4):
+        for _ in range(6):
             wl.loop_probe(TT)
         n, ms = profile_read(wl)
         mhz = profile_clock_mhz(wl)
