@@ -1,0 +1,92 @@
+"""Differential test of the two kernel families (bsdfd_desc.tile = 16: csrc/bsdfd.hip on the 16x16 MFMA shapes; 32: csrc/flow32.hip
+on v_mfma_f32_32x32x16_f16): the same operators on the same inputs, over randomly drawn sizes, step counts and call forms.  Each
+family is held to the fp64 oracle elsewhere (tests/test_gpu_parity.py runs three ways); here they are held to EACH OTHER on every
+row — a defect confined to a few lanes of one family (a partial tile, one half-wave of a reduction, a rarely taken branch) shows up
+as rows that disagree by O(1).  Two fp32-class evaluations of a sharp lobe legitimately differ by more than 1e-4 on the rare rows
+where a step's det(I + J/T) is nearly singular (measured: median 2-4e-6, p99 1e-5 .. 2e-4, isolated rows up to 0.3 at a rate of ~1e-4
+on chm_orange spherical), so the criterion is: median <= 5e-5, p99 <= 1e-3 and at most 0.2 % of the rows beyond 2 % (batches of 100 rows and more; smaller
+ones: every row within 2 %) — one wrong lane of 64 is 1.6 % of the rows, one wrong row of a 33-row batch 3 %."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from conftest import load_case  # noqa: E402
+
+
+def same_density(a, b):
+    a, b = a.detach().double().cpu().numpy(), b.detach().double().cpu().numpy()
+    if a.shape != b.shape or not (np.isfinite(a).all() and np.isfinite(b).all()):
+        return False
+    ok = np.abs(b) > 1e-6 * max(np.percentile(np.abs(b), 99), 1e-300)
+    if not ((a == 0) == (b == 0))[ok].all():
+        return False
+    rel = np.abs(a - b)[ok] / np.abs(b[ok])
+    if rel.size == 0:
+        return True
+    if rel.size < 100:     # a handful of rows: every one of them within 2 % (the statistics below need a population)
+        return bool((rel <= 2e-2).all())
+    return bool(np.median(rel) <= 5e-5 and np.percentile(rel, 99) <= 1e-3 and (rel > 2e-2).sum() <= int(np.ceil(0.002 * rel.size)))
+
+
+def same_dirs(a, b):
+    d = (a - b).abs().max(dim=1).values
+    if d.numel() < 100:
+        return bool(torch.isfinite(a).all() and (d <= 1e-3).all().item())
+    return bool(torch.isfinite(a).all() and d.median().item() <= 1e-5 and (d > 1e-4).sum().item() <= int(np.ceil(0.002 * d.numel())))
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU visible")
+    return torch.device("cuda", 0)
+
+
+def _dirs(rng, n, lo):
+    z, ph = rng.uniform(lo, 1.0, size=n), rng.uniform(0, 2 * np.pi, size=n)
+    r = np.sqrt(1 - z * z)
+    return torch.from_numpy(np.stack([r * np.cos(ph), r * np.sin(ph), z], 1).astype(np.float32)).to(_dev())
+
+
+@pytest.mark.parametrize("stem,variant", [("aniso_miro_7_rgb_disk", 0), ("chm_orange_rgb_disk", 0), ("aniso_miro_7_rgb_spherical", 0),
+                                          ("chm_orange_rgb_spherical", 0), ("bsdf_3_spherical", 1)])
+def test_the_two_tilings_agree_row_for_row(stem, variant):
+    from bsdf_diffusion_sampling_amd.sampler import FlowSampler
+    g, fw = load_case(stem)
+    s16, s32 = FlowSampler(fw, tile=16), FlowSampler(fw, tile=32)
+    assert (s16.tile, s32.tile, s32.tile_samples_only) == (16, 32, 32)
+    rng = np.random.default_rng(hash(stem) % 1000)
+    sizes = [1, 2, 31, 32, 33, 63, 64, 65, 95, 97, 1000] + [int(v) for v in rng.integers(100, 20000, size=6)]
+    for k, n in enumerate(sizes):
+        T = int(rng.integers(1, 13))
+        wi, wl = _dirs(rng, n, 0.05), _dirs(rng, n, -1.0 if variant else 0.02)
+        seed, offset = int(rng.integers(0, 1 << 30)), int(rng.integers(0, 1 << 20))
+        # in-kernel base draws are bit-identical (same Philox counters and arithmetic) -> the flows start from the same point
+        wo16, p16 = s16.plugin_sample(wi, None, T=T, variant=variant, seed=seed, offset=offset)
+        wo32, p32 = s32.plugin_sample(wi, None, T=T, variant=variant, seed=seed, offset=offset)
+        assert torch.isfinite(wo32).all() and torch.isfinite(p32).all()
+        assert same_dirs(wo16, wo32), (n, T, (wo16 - wo32).abs().max().item())
+        assert same_density(p32, p16), (n, T)
+        q16, q32 = s16.plugin_pdf(wi, wl, T=T, variant=variant), s32.plugin_pdf(wi, wl, T=T, variant=variant)
+        assert same_density(q32, q16), (n, T)
+        if k % 3 == 0:   # the fused call, the per-query context and the operator-level forms
+            f16_, f32_ = s16.plugin_sample_pdf(wi, wl, None, T=T, variant=variant, seed=seed, offset=offset), \
+                s32.plugin_sample_pdf(wi, wl, None, T=T, variant=variant, seed=seed, offset=offset)
+            assert same_dirs(f16_[0], f32_[0]) and same_density(f32_[1], f16_[1]) and same_density(f32_[2], f16_[2])
+            assert same_dirs(f32_[0], wo32) and same_density(f32_[1], p32) and same_density(f32_[2], q32)
+            ctx = s32.new_context(n)
+            a = s32.plugin_sample(wi, None, T=T, variant=variant, seed=seed, offset=offset, ctx_out=ctx)
+            assert torch.equal(a[0], wo32) and torch.equal(a[1], p32)
+            assert torch.equal(s32.plugin_pdf(wi, wl, T=T, variant=variant, ctx_in=ctx), q32)
+            m = min(n, 2048)
+            cond, x0 = torch.from_numpy(g["wi"][:m]).to(_dev()), torch.from_numpy(g["x0"][:m]).to(_dev())
+            xa, pa = s16.network_sampling(cond, x0, T=T)
+            xb, pb = s32.network_sampling(cond, x0, T=T)
+            assert same_dirs(xa, xb) and same_density(pb, pa)
+            assert same_density(s32.network_pdf(xa, cond, T=T), s16.network_pdf(xa, cond, T=T))
+            xs = s32.flow_samples_only(cond, x0, T=T)
+            assert torch.allclose(xs, xb, atol=1e-6, rtol=0)      # the samples-only kernel walks the sampling kernel's trajectory
+    s16.close()
+    s32.close()
