@@ -580,6 +580,46 @@ def run_secondary(name, device, precision):
     return out
 
 
+def board_power_probe(wl, seconds=1.5):
+    """rocm-smi socket power / sclk (median of the samples) while the workload's sample launch runs back to back for `seconds`;
+    values are null where rocm-smi is absent or prints another schema."""
+    import threading
+    import torch
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=15)
+                d = next(iter(json.loads(r.stdout).values()))
+                w = next((float(v) for k, v in d.items() if "Power" in k and "(W)" in k), None)
+                mhz = next((float("".join(c for c in v if c.isdigit() or c == ".")) for k, v in d.items() if k.startswith("sclk clock speed")), None)
+                samples.append((w, mhz))
+            except Exception:
+                pass
+            stop.wait(0.3)
+    launches = 0
+    for _ in range(20):
+        wl.loop_probe(wl.T)
+    torch.cuda.synchronize()
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            wl.loop_probe(wl.T)
+        launches += 20
+        torch.cuda.synchronize()
+    stop.set()
+    th.join(timeout=20)
+    ws = sorted(w for w, _ in samples if w is not None)
+    cs = sorted(c for _, c in samples if c is not None)
+    return {"socket_power_w": ws[len(ws) // 2] if ws else None, "sclk_mhz": cs[len(cs) // 2] if cs else None, "samples": len(samples),
+            "launches": launches + 20,
+            "basis": f"rocm-smi polled every 0.3 s during {seconds} s of back-to-back sample launches of the judged workload, behind the "
+                     "timed region; MI355X board limit 1 400 W, boost clock 2 400 MHz"}
+
+
 def secondary_issue_bound(name, wl):
     """Euler-step cost of a secondary workload's kernel in shader cycles per (tile x step) — the same launch at T and at 2T, each
     converted at the clock its own launches ran at; the per-query prologue cancels — next to the instruction-issue model of that
@@ -936,6 +976,14 @@ def worker(a):
                 roof["issue_bound"] = ib
             except Exception as exc:
                 roof["issue_bound"] = {"error": repr(exc)}
+            # the board's own view while the judged kernel runs back to back (outside the timed region): the flow kernel is
+            # power-limited — socket power at the limit, shader clock below boost
+            if rank == 0 and world == 1:
+                try:
+                    roof["board"] = board_power_probe(wl)
+                    roof["flow_launches_after_timed_region"] += roof["board"].pop("launches", 0)
+                except Exception as exc:
+                    roof["board"] = {"error": repr(exc)}
         out["roofline"] = roof
         if world == 1 and not a.no_secondary:
             sec = {}

@@ -269,10 +269,6 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
         if (chunk_base >= ntiles) break;
         const long long tile = chunk_base + (it & ((1 << cl) - 1)) * waves_per_block + wave;
         if (tile >= ntiles) continue;
-        // row of this lane's query (clamped on the ragged last tile).  The epilogue and the fused kernel's phase switch RECOMPUTE it
-        // from the wave-uniform tile base and an opaque copy of the lane number instead of keeping the 64-bit row — and every
-        // address derived from it — in registers across the Euler loop, where there are none to spare (`opaque` stops the
-        // compiler from sharing the computation with the prologue's)
         // The lane number is re-derived per tile from an opaque copy: everything computed from it (LDS addresses in five
         // scalings, the half-wave selects) would otherwise be hoisted out of the tile loop and held in registers for the whole
         // kernel — the fused spherical instantiation spilled 19 of them at kernel entry.
@@ -280,14 +276,17 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
         const int lane = opaque(lane0);
         const int h = lane >> 5;
         const int n = lane & 31;
+        // Row of this lane's query (clamped on the ragged last tile).  The epilogue and the fused kernel's phase switch RECOMPUTE it
+        // from the wave-uniform tile base and another opaque copy of the lane number instead of keeping the 64-bit row — and every
+        // address derived from it — in registers across the Euler loop, where there are none to spare.
         const long long tile_q0 = q_begin + tile * 32;
         auto row_of = [&](int nn, bool& in_range) -> long long {
             const long long r = tile_q0 + nn;
             in_range = r < q_end;
             return in_range ? r : q_end - 1;
         };
-        bool valid;
-        const long long qi = row_of(n, valid);
+        bool in_range0;
+        const long long qi = row_of(n, in_range0);
 
         // ---------------- inputs ---------------------------------------------------------------------
         // yh: this lane's coordinate of the condition omega_i (lane h encodes dimension h); xs: this lane's coordinate of the
@@ -378,7 +377,8 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
 #pragma unroll
                 for (int j = 0; j < 11; ++j) cacc = mfma32f(Lwc[j * 64 + lane], e[j], cacc);
             }
-            // ---------------- base-density net PE_3 -> 16 (SiLU) -> 4, exact fp32 -------------------------
+            // ---------------- base-density net PE_3 -> 16 (SiLU) -> 4: first layer on split-fp16 MFMAs with all four products of the
+            //                  two-way splits (BSDFD_T32_BASE_SPLIT; 0: seven exact-fp32 MFMAs), second layer fp32 VALU ------------
             {
                 const float* Lbw1 = reinterpret_cast<const float*>(smem + LY::BW1);
                 const f32x4* Lbb1 = reinterpret_cast<const f32x4*>(smem + LY::BB1 + h * 32);

@@ -64,6 +64,8 @@ def test_bench_line_single_gpu_with_secondary_and_cpu_baseline():
     assert ac["value"] is not None and ac["value"] > 0, ac
     assert d["roofline"]["traffic_source"]["measured_in_this_run"] is False and "@" in d["roofline"]["traffic_source"]["ref"]
     assert ib["tile_queries"] == d["config"]["tile_queries"] == 32     # the judged kernel: csrc/flow32.hip
+    board = d["roofline"]["board"]   # rocm-smi while the judged kernel runs back to back: null values where the tool is absent
+    assert "error" not in board and (board["socket_power_w"] is None or 200 < board["socket_power_w"] < 1600), board
     for name in ("disk_1Mi_T4", "spherical_16Mi_T8", "mixed_16Mi", "teacher_64x6_4Mi_T128", "complex64_1Mi_T8"):
         s = d["secondary"][name]
         assert "error" not in s, s
