@@ -30,17 +30,17 @@ from .sharding import bucket_by_material
 
 
 class MaterialTable:
-    def __init__(self, stems: Sequence[str], precision: str = "default"):
+    def __init__(self, stems: Sequence[str], precision: str = "default", tile: int = 0):
         """``stems`` are shipped weight-set names such as ``aniso_miro_7_rgb_disk`` or
         ``chm_orange_rgb_spherical`` (mixing domains is allowed: the domain, T and plugin
-        variant are per material)."""
+        variant are per material).  ``tile``: bsdfd_desc.tile for every material (0 = library default)."""
         self.stems = list(stems)
         self.samplers: List[FlowSampler] = []
         self.T: List[int] = []
         self.variant: List[int] = []
         for stem in self.stems:
             fw = W.load(W.shipped_path(*self._split(stem)))
-            self.samplers.append(FlowSampler(fw, precision=precision))
+            self.samplers.append(FlowSampler(fw, precision=precision, tile=tile))
             disk = fw.domain == W.DOMAIN_DISK
             self.T.append(4 if disk else 8)  # plugin defaults, brdf_measured_disk.py:68 / _spherical.py:78
             self.variant.append(_lib.PLUGIN_FULLSPHERE if stem.startswith("bsdf_") else _lib.PLUGIN_MEASURED)

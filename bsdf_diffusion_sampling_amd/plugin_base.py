@@ -88,7 +88,8 @@ class NeuralBSDFCore:
                 self.bsdf = MeasuredBSDF(path)
         self.albedo = torch.tensor(get("albedo", [1.0, 1.0, 1.0]), dtype=torch.float32)
         fw = self._load_weights(get("weights", None), get("checkpoint_dir", None))
-        self.sampler = FlowSampler(fw, precision=self.precision)
+        # props["tile"]: bsdfd_desc.tile — 0 (library default: 32-query tiles for these nets), 16 or 32 queries per wave tile
+        self.sampler = FlowSampler(fw, precision=self.precision, tile=int(get("tile", 0)))
         # per-query context (include/bsdfd.h, bsdfd_context_bytes): a renderer asks pdf(si, wl) and sample(si) for the same
         # intersections (rendering/brdf_measured_disk.py:112,59; Mitsuba's path integrator in the order eval_pdf() -> sample()),
         # so whichever call sees an si.wi first also writes what depends on wi alone and the later ones read it.  Keyed on the
