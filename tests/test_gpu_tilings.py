@@ -57,10 +57,14 @@ def test_the_two_tilings_agree_row_for_row(stem, variant):
     g, fw = load_case(stem)
     s16, s32 = FlowSampler(fw, tile=16), FlowSampler(fw, tile=32)
     assert (s16.tile, s32.tile, s32.tile_samples_only) == (16, 32, 32)
-    rng = np.random.default_rng(hash(stem) % 1000)
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(stem.encode()))   # (deterministic inputs: str hashes are salted per process)
     sizes = [1, 2, 31, 32, 33, 63, 64, 65, 95, 97, 1000] + [int(v) for v in rng.integers(100, 20000, size=6)]
     for k, n in enumerate(sizes):
-        T = int(rng.integers(1, 13))
+        # (with T < 4 a single step's det(I + J/T) is ill-conditioned and any two fp32 evaluations differ by percents on the odd
+        #  row — tests/test_gpu_parity.py::test_step_counts_incl_non_powers_of_two; the small batches, where every row must agree
+        #  within 2 %, therefore use T >= 4)
+        T = int(rng.integers(4 if n < 100 else 1, 13))
         wi, wl = _dirs(rng, n, 0.05), _dirs(rng, n, -1.0 if variant else 0.02)
         seed, offset = int(rng.integers(0, 1 << 30)), int(rng.integers(0, 1 << 20))
         # in-kernel base draws are bit-identical (same Philox counters and arithmetic) -> the flows start from the same point
