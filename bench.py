@@ -538,6 +538,12 @@ def profile_lookup(fname, workload):
     return doc.get(workload), prov
 
 
+def tile_key(workload, tile_q):
+    """Key of a workload's entry in the looked-up profiles: the 16-query-tile kernels of the nets whose default is the 32-query
+    family are filed as `<workload>@tile16` (runs with BSDFD_TILE=16)."""
+    return workload + "@tile16" if tile_q == 16 and workload in ("disk_1Mi_T8", "disk_1Mi_T4", "spherical_16Mi_T8", "teacher_64x6_4Mi_T128") else workload
+
+
 def isa_model(workload):
     """Instruction-issue model of the Euler-step loop of the dominant kernel: profiles/isa_mix_latest.json, written by
     tools/isa_mix.py from the assembly of the shipped build (MFMA + VALU issue cycles per 16-query tile and step)."""
@@ -646,7 +652,7 @@ def secondary_issue_bound(name, wl):
     ib = {"tile_queries": tile_q, "measured_loop_cycles_per_tile_step": meas,
           "loop_basis": f"(launch at T={t_hi} minus at T={t_lo}) / {t_hi - t_lo}: {cyc[t_hi][0]:.4f} ms @ {cyc[t_hi][1]:.0f} MHz, "
                         f"{cyc[t_lo][0]:.4f} ms @ {cyc[t_lo][1]:.0f} MHz"}
-    mdl, prov = isa_model(name)
+    mdl, prov = isa_model(tile_key(name, tile_q))
     ib["model_source"] = prov
     if mdl and mdl.get("tile_queries", 16) == tile_q:
         ib.update({"model_issue_cycles_per_tile_step": mdl["issue_cycles_total"], "model_mfma_cycles": mdl["issue_cycles_mfma"],
@@ -852,7 +858,9 @@ def worker(a):
         avg_ms = kern_ms / max(n_launch, 1)
         flops_launch = wl.flops_per_pass / wl.launches_per_pass
         achieved = wl.flops_per_pass * R * a.steps / (kern_ms * 1e-3) / 1e12
-        pmc_entry, pmc_prov = profile_lookup("pmc_latest.json", a.workload)
+        pmc_entry, pmc_prov = profile_lookup("pmc_latest.json", tile_key(a.workload, getattr(getattr(wl, "smp", None), "tile", 32)))
+        if pmc_entry is None and pmc_prov.get("status") == "current":   # (no PMC pass of this tiling on file: the bytes do not depend on it)
+            pmc_entry, pmc_prov = profile_lookup("pmc_latest.json", a.workload)
         ctx_on = getattr(wl, "ctx", None) is not None
         # (the committed PMC passes are those of the DEFAULT command, i.e. without the per-query context: withheld under --context on)
         traffic = None if ctx_on else (pmc_entry or {}).get("hbm_bytes_per_launch")
@@ -963,7 +971,7 @@ def worker(a):
                               "VALU-heavy mix MFMA time and VALU time add — a 16x16x32 MFMA 16.4 cycles, a 32x32x16 32.1, a transcendental "
                               "~11 between plain VALU (tools/ubench/RESULTS.md rounds 3-4) — model/measured_loop ~ 1 means the step runs "
                               "at the hardware's issue rate for this instruction mix.  A tile is `tile_queries` queries (one wave64)."}
-                mdl, mdl_prov = isa_model(a.workload)
+                mdl, mdl_prov = isa_model(tile_key(a.workload, tile_q))
                 ib["model_source"] = mdl_prov
                 if mdl and mdl.get("tile_queries", 16) != tile_q:
                     ib["model_source"] = dict(mdl_prov, status=f"model is of the {mdl.get('tile_queries', 16)}-query-tile kernel, the run used {tile_q}")

@@ -58,6 +58,7 @@ KERNEL_OF_WORKLOAD = {  # bench.py workload -> mangled-name fragment of its flow
     "complex64_1Mi_T8": "flow_kernelILi1ELi4ELi2ELb1ELi6ELb0E",
     # the 16-query-tile kernels of the same nets (bsdfd_desc.tile = 16), for comparison
     "disk_1Mi_T8@tile16": "flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E",
+    "disk_1Mi_T4@tile16": "flow_kernelILi0ELi2ELi2ELb1ELi3ELb0E",
     "spherical_16Mi_T8@tile16": "flow_kernelILi1ELi2ELi2ELb1ELi4ELb0E",
 }
 
