@@ -275,9 +275,9 @@ def expected_flow_kernels(variant: str = "async") -> Dict[str, Dict[str, int]]:
                             elif dom == 1 and nh == 4:    # block MIMS: 21 (11) reads, 5 (4) waits
                                 spec = {"async": 21 if split else 11, "waits": 5 if split else 4}
                         out[f"flow_kernelILi{dom}ELi{nm}ELi{prec}ELb{jac}ELi{nh}ELb{fused}EE"] = spec
-    for dom in (0, 1):                                    # csrc/flow32.hip: <DOMAIN, JAC, FUSED>, compiler-managed LDS reads
-        for jac, fused in ((0, 0), (1, 0), (1, 1)):
-            out[f"flow_kernel32ILi{dom}ELb{jac}ELb{fused}EE"] = {"async": 0, "waits": 0}
+    for dom in (0, 1):                                    # csrc/flow32.hip, compiler-managed LDS reads
+        for jac, fused, split in ((0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 0, 0)):   # <DOMAIN, JAC, FUSED, SPLIT>; (0, 0, 0): precision f16, samples-only
+            out[f"flow_kernel32ILi{dom}ELb{jac}ELb{fused}ELb{split}EE"] = {"async": 0, "waits": 0}
     out["flow_kernel32wE"] = {"async": 0, "waits": 0}        # the 64 x 6 fp16 teacher on 32-query tiles
     return out
 

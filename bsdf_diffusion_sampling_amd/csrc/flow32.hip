@@ -109,13 +109,15 @@ __device__ __forceinline__ void both32(float x, float& lo, float& up) {
 }
 
 // the lane's 16 values of a vector -> the B fragments (hi, lo) of the two K = 16 chunks of the next contraction
+// (SPLIT = false, precision f16: rounded to fp16, no lo part)
+template <bool SPLIT = true>
 __device__ __forceinline__ void split16(const float (&x)[16], Frag (&hi)[2], Frag (&lo)[2]) {
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const float x4[4] = {x[8 * c + 4 * k], x[8 * c + 4 * k + 1], x[8 * c + 4 * k + 2], x[8 * c + 4 * k + 3]};
-            split_pack<true>(x4, hi[c].p[2 * k], hi[c].p[2 * k + 1], lo[c].p[2 * k], lo[c].p[2 * k + 1]);
+            split_pack<SPLIT>(x4, hi[c].p[2 * k], hi[c].p[2 * k + 1], lo[c].p[2 * k], lo[c].p[2 * k + 1]);
         }
 }
 
@@ -140,10 +142,13 @@ __device__ __forceinline__ Mat32 load_mat(const char* smem, int off, int lane) {
     return r;
 }
 // (W_hi + W_lo) (x_hi + x_lo) without the lo lo term: hi hi + hi lo + lo hi in ONE fp32 accumulator, 6 MFMAs
+// (SPLIT = false, precision f16: the hi hi product alone, 2 MFMAs)
+template <bool SPLIT = true>
 __device__ __forceinline__ f32x16 mm6(const Mat32& w, const Frag (&xh)[2], const Frag (&xl)[2]) {
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 a = mfma32(w.h0, xh[0].v, zero16);
     a = mfma32(w.h1, xh[1].v, a);
+    if (!SPLIT) return a;
     a = mfma32(w.h0, xl[0].v, a);
     a = mfma32(w.h1, xl[1].v, a);
     a = mfma32(w.l0, xh[0].v, a);
@@ -210,11 +215,14 @@ __device__ __forceinline__ float von_mises_sample32(float mu, float kappa, unsig
 
 // ---------------------------------------------------------------------------------------------
 // The kernel.  DOMAIN: BSDFD_DOMAIN_*; JAC: track the Jacobian determinant (false: bsdfd_flow_samples_only — the same trajectory
-// as the sampling kernel, bit for bit); FUSED: the two-phase OP_SAMPLE_PDF loop (its own instantiation).
+// as the sampling kernel, bit for bit); FUSED: the two-phase OP_SAMPLE_PDF loop (its own instantiation); SPLIT: split-fp16
+// contractions (precision split3) — false: single fp16 products (precision f16; instantiated without the Jacobian only: the reflow
+// teacher sampling of the 32-wide nets, learning_repo_cleanup/disk_domain_sampling.py:93-110).
 // Per lane the step keeps 16-register vectors where the 16-query kernels keep 8; BSDFD_T32_WAVES = 3 waves per SIMD (168 VGPRs).
 // ---------------------------------------------------------------------------------------------
-template <int DOMAIN, bool JAC, bool FUSED>
+template <int DOMAIN, bool JAC, bool FUSED, bool SPLIT>
 __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? BSDFD_T32_FUSED_SPH_WAVES : BSDFD_T32_WAVES) void flow_kernel32(const KParams p) {
+    static_assert(SPLIT || !JAC, "the single-product (f16) instantiations exist without the Jacobian only");
     using LY = L32<DOMAIN>;
     constexpr bool SPH = DOMAIN == BSDFD_DOMAIN_SPHERICAL;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -526,8 +534,8 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
             if (!SPH) {
                 // ---- MIM, disk 25-32-32-32-2: U_i = F_i g1, R_j = G_j g3, J_ji = sum_k R_j[k] g2[k] U_i[k] (bsdfd.hip, block MIM)
                 act16<JAC>(z, hv, gv);
-                split16(hv, bh, bl);
-                z = mm6(load_mat(smem, LY::WH, lane), bh, bl);
+                split16<SPLIT>(hv, bh, bl);
+                z = mm6<SPLIT>(load_mat(smem, LY::WH, lane), bh, bl);
                 if constexpr (JAC) {
                     split16(gv, gh, gl);
                     mm6x2(load_mat(smem, LY::WF, lane), gh, gl, load_mat(smem, LY::WF + 4 * FR32, lane), gh, gl, U0, U1);
@@ -535,8 +543,8 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
                 // hidden layer 2 (its silu' stays in fp32)
                 act16<JAC>(z, hv, gm);
                 if constexpr (JAC) premul();
-                split16(hv, bh, bl);
-                z = mm6(load_mat(smem, LY::WH + 4 * FR32, lane), bh, bl);
+                split16<SPLIT>(hv, bh, bl);
+                z = mm6<SPLIT>(load_mat(smem, LY::WH + 4 * FR32, lane), bh, bl);
             } else {
                 // ---- MIMS, spherical 26-32-32-32-32-2: two forward-mode tangent layers, then the output fold (bsdfd.hip, block MIMS)
                 f32x16 zt0, zt1;
@@ -558,9 +566,9 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
 #pragma unroll
                 for (int layer = 0; layer < 2; ++layer) {
                     act16<JAC>(z, hv, gv);
-                    split16(hv, bh, bl);
+                    split16<SPLIT>(hv, bh, bl);
                     const Mat32 w = load_mat(smem, LY::WH + layer * 4 * FR32, lane);
-                    z = mm6(w, bh, bl);
+                    z = mm6<SPLIT>(w, bh, bl);
                     if constexpr (JAC) {
                         float t0v[16], t1v[16];
 #pragma unroll
@@ -578,8 +586,8 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
                 // hidden layer 3 (its silu' stays in fp32)
                 act16<JAC>(z, hv, gm);
                 if constexpr (JAC) premul();
-                split16(hv, bh, bl);
-                z = mm6(load_mat(smem, LY::WH + 2 * 4 * FR32, lane), bh, bl);
+                split16<SPLIT>(hv, bh, bl);
+                z = mm6<SPLIT>(load_mat(smem, LY::WH + 2 * 4 * FR32, lane), bh, bl);
             }
             // ---- last hidden layer -> R0, R1 (MFMA), v (fp32 VALU dot over the lane's 16 units + one swap) ----
             act16<JAC>(z, hv, gv);
@@ -981,12 +989,15 @@ std::vector<char> build_image32w(const bsdfd_desc& d) {
     return img;
 }
 
-// which 32-query-tile kernel serves (net, precision, mode): 0 none, 1 flow_kernel32, 2 flow_kernel32w
+// which 32-query-tile kernel serves (net, precision, mode): 0 none, 1 flow_kernel32 (split3), 2 flow_kernel32w, 3 flow_kernel32 (f16)
 int kind32(const bsdfd_desc& d, int prec, int mode) {
     if (prec == BSDFD_PREC_SPLIT3 && d.width == 32 &&
         ((d.domain == BSDFD_DOMAIN_DISK && d.n_hidden == 3) || (d.domain == BSDFD_DOMAIN_SPHERICAL && d.n_hidden == 4)))
         return 1;
     if (prec == BSDFD_PREC_F16 && d.width == 64 && d.n_hidden == 6 && d.domain == BSDFD_DOMAIN_SPHERICAL && mode == 0) return 2;
+    if (prec == BSDFD_PREC_F16 && d.width == 32 && mode == 0 &&
+        ((d.domain == BSDFD_DOMAIN_DISK && d.n_hidden == 3) || (d.domain == BSDFD_DOMAIN_SPHERICAL && d.n_hidden == 4)))
+        return 3;   // flow_kernel32 with single fp16 products (samples-only)
     return 0;
 }
 
@@ -996,6 +1007,7 @@ bool bsdfd_tile32_supported(const bsdfd_desc& d, int prec) {
     return kind32(d, prec, 0) != 0 || kind32(d, prec, 1) != 0;
 }
 
+
 std::vector<char> bsdfd_build_image32(const bsdfd_desc& d, int prec) {
     if (kind32(d, prec, 0) == 2) return build_image32w(d);
     return d.domain == BSDFD_DOMAIN_DISK ? build_image32_t<BSDFD_DOMAIN_DISK>(d) : build_image32_t<BSDFD_DOMAIN_SPHERICAL>(d);
@@ -1003,7 +1015,7 @@ std::vector<char> bsdfd_build_image32(const bsdfd_desc& d, int prec) {
 
 int bsdfd_kernel32_lds_bytes(const bsdfd_desc& d, int prec, int mode) {
     if (kind32(d, prec, mode) == 2) return L32W::TOTAL;
-    const int domain = d.domain;
+    const int domain = d.domain;   // (kind 3 = mode 0 of the same kernel template: same image, same slab)
     if (mode == 2)
         return domain == BSDFD_DOMAIN_DISK ? L32<BSDFD_DOMAIN_DISK>::TOTAL + 4 * CaccLds<BSDFD_DOMAIN_DISK, true>::slab
                                            : L32<BSDFD_DOMAIN_SPHERICAL>::TOTAL + 4 * CaccLds<BSDFD_DOMAIN_SPHERICAL, true>::slab;
@@ -1016,15 +1028,18 @@ int bsdfd_kernel32_threads(const bsdfd_desc& d, int prec, int mode) { return kin
 const void* bsdfd_kernel32(const bsdfd_desc& d, int prec, int mode) {
     const int kind = kind32(d, prec, mode);
     if (kind == 2) return reinterpret_cast<const void*>(flow_kernel32w);
-    if (kind != 1) return nullptr;
     const bool disk = d.domain == BSDFD_DOMAIN_DISK;
+    if (kind == 3)
+        return disk ? reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_DISK, false, false, false>)
+                    : reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_SPHERICAL, false, false, false>);
+    if (kind != 1) return nullptr;
     switch (mode) {
-        case 0: return disk ? reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_DISK, false, false>)
-                            : reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_SPHERICAL, false, false>);
-        case 1: return disk ? reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_DISK, true, false>)
-                            : reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_SPHERICAL, true, false>);
-        case 2: return disk ? reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_DISK, true, true>)
-                            : reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_SPHERICAL, true, true>);
+        case 0: return disk ? reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_DISK, false, false, true>)
+                            : reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_SPHERICAL, false, false, true>);
+        case 1: return disk ? reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_DISK, true, false, true>)
+                            : reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_SPHERICAL, true, false, true>);
+        case 2: return disk ? reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_DISK, true, true, true>)
+                            : reinterpret_cast<const void*>(flow_kernel32<BSDFD_DOMAIN_SPHERICAL, true, true, true>);
     }
     return nullptr;
 }
