@@ -178,6 +178,7 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
         return out
     # compile to a temporary name and rename into place: a concurrent process (another rank of a torchrun
     # launch, a parallel test worker) never dlopens a half-written library
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     tmp = f"{out}.tmp.{os.getpid()}"
     info = {"variant": "async", "violations": {}, "hipcc": None, "unverified": False}
     allow_unverified = os.environ.get("BSDFD_ALLOW_UNVERIFIED_BUILD") == "1"
