@@ -277,8 +277,10 @@ def expected_flow_kernels(variant: str = "async") -> Dict[str, Dict[str, int]]:
                         out[f"flow_kernelILi{dom}ELi{nm}ELi{prec}ELb{jac}ELi{nh}ELb{fused}EE"] = spec
     for dom in (0, 1):                                    # csrc/flow32.hip, compiler-managed LDS reads
         for jac, fused, split in ((0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 0, 0)):   # <DOMAIN, JAC, FUSED, SPLIT>; (0, 0, 0): precision f16, samples-only
-            out[f"flow_kernel32ILi{dom}ELb{jac}ELb{fused}ELb{split}EE"] = {"async": 0, "waits": 0}
-    out["flow_kernel32wE"] = {"async": 0, "waits": 0}        # the 64 x 6 fp16 teacher on 32-query tiles
+            # "sel": destination-select writes (the packed-fp16 sigmoids' SDWA halves, BSDFD_PK4_TRANS: 2 x 4 per fragment, one
+            # fragment per 8 units) the forwarding-hazard check must see: 2 (3) hidden layers in front of the last one x 2 fragments
+            out[f"flow_kernel32ILi{dom}ELb{jac}ELb{fused}ELb{split}EE"] = {"async": 0, "waits": 0, "sel": 0 if split else (32, 48)[dom]}
+    out["flow_kernel32wE"] = {"async": 0, "waits": 0, "sel": 160}   # the 64 x 6 fp16 teacher on 32-query tiles: 5 layers x 4 fragments
     return out
 
 
@@ -288,7 +290,7 @@ def census_lines(lines: List[str], fragment: str = "flow_kernel") -> Dict[str, D
     out = {}
     for k in kernel_names(lines, fragment):
         body = kernel_body(lines, k)
-        n_mfma = n_async = n_wait = 0
+        n_mfma = n_async = n_wait = n_sel = 0
         in_asm = False
         for raw in body:
             l = raw.strip()
@@ -308,7 +310,9 @@ def census_lines(lines: List[str], fragment: str = "flow_kernel") -> Dict[str, D
                 n_async += 1
             if in_asm and op.startswith("s_waitcnt") and "lgkmcnt(0)" in code:
                 n_wait += 1
-        out[k] = {"mfma": n_mfma, "async": n_async, "waits": n_wait, "meta": kernel_meta(lines, k)}
+            if in_asm and op.startswith("v_") and _dst_sel_write(op, code):
+                n_sel += 1
+        out[k] = {"mfma": n_mfma, "async": n_async, "waits": n_wait, "sel": n_sel, "meta": kernel_meta(lines, k)}
     return out
 
 
@@ -342,6 +346,8 @@ def verify_census(asm_paths: List[str], variant: str = "async", allow_scratch: b
         if c["async"] < spec["async"] or c["waits"] < spec["waits"]:
             problems.append(f"{frag}: {c['async']} asynchronous ds_read_b128 / {c['waits']} waits recognised, the source issues "
                             f"{spec['async']} / {spec['waits']}")
+        if c.get("sel", 0) < spec.get("sel", 0):
+            problems.append(f"{frag}: {c.get('sel', 0)} destination-select writes recognised in its inline asm, the source issues {spec['sel']}")
         if not c["meta"] or "vgpr_count" not in c["meta"]:
             problems.append(f"{frag}: .amdhsa metadata not found")
         elif not allow_scratch and c["meta"].get("private_segment_fixed_size", 0) != 0:
@@ -423,3 +429,86 @@ def check_swap_hazards_lines(lines: List[str], key: str) -> Tuple[int, List[str]
 def check_file_swap(path: str, fragment: str = "flow_kernel") -> Dict[str, Tuple[int, List[str]]]:
     lines = open(path).read().splitlines()
     return {k: check_swap_hazards_lines(lines, k) for k in kernel_names(lines, fragment)}
+
+
+# Forwarding hazards of gfx940-class parts (LLVM GCNHazardRecognizer::checkVALUHazards, hasTransForwardingHazard /
+# hasDstSelForwardingHazard): a non-transcendental VALU instruction that reads the result of a transcendental, and ANY VALU
+# instruction that reads a register written through a destination select (SDWA dst_sel other than DWORD, op_sel to the high
+# half), must be at least one wait state behind it.  The compiler pads its own code; the packed-fp16 sigmoids of csrc/flow32.hip
+# (BSDFD_PK4_TRANS) are inline asm, which its hazard recogniser does not look into — so the build checks every kernel.
+FORWARD_WAIT = 1
+_TRANS = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")
+
+
+def _is_trans(op: str) -> bool:
+    return op.startswith(_TRANS)
+
+
+def _dst_sel_write(op: str, code: str) -> bool:
+    if op.endswith("_sdwa"):
+        m = re.search(r"dst_sel:(\w+)", code)
+        return bool(m) and m.group(1) != "DWORD"
+    m = re.search(r"op_sel:\[([01,\s]+)\]", code)      # VOP3 / VOP3P op_sel: the LAST bit is the destination's
+    return bool(m) and op.startswith("v_") and not op.startswith("v_pk_") and m.group(1).replace(" ", "").split(",")[-1] == "1"
+
+
+def check_forwarding_hazards_lines(lines: List[str], key: str) -> Tuple[int, List[str]]:
+    """(number of destination-select writes, violations) of one kernel: see FORWARD_WAIT."""
+    body = kernel_body(lines, key)
+    ins, label_at = [], {}
+    for raw in body:
+        code = raw.split(";")[0].strip()
+        if not code or code.startswith("."):
+            m = re.match(r"^(\.LBB\d+_\d+):", code)
+            if m:
+                label_at[m.group(1)] = len(ins)
+            continue
+        if code.endswith(":"):
+            label_at[code[:-1]] = len(ins)
+            continue
+        toks = [t.strip(",") for t in code.split()]
+        ins.append((toks[0], toks[1:], code))
+    n_sel, bad = 0, []
+    for i, (op, toks, code) in enumerate(ins):
+        if not op.startswith("v_") or not toks:
+            continue
+        trans, sel = _is_trans(op), _dst_sel_write(op, code)
+        n_sel += sel
+        if not (trans or sel):
+            continue
+        dst = _regs(toks[0])
+        if not dst:
+            bad.append(f"`{code}`: destination operand not understood — cannot verify its wait state")
+            continue
+        # the instruction(s) within FORWARD_WAIT wait states on every path
+        stack = [(i + 1, 0)]
+        while stack:
+            j, w = stack.pop()
+            while j < len(ins) and w < FORWARD_WAIT:
+                o, t, c = ins[j]
+                if o.startswith("v_") and t:
+                    has_dst = not o.startswith("v_cmp") and not o.startswith("v_readlane") and not o.startswith("v_readfirstlane")
+                    reads = set().union(*[_regs(x) for x in (t[1:] if has_dst else t)])
+                    if has_dst and (o.startswith("v_fmac") or o.startswith("v_pk_fmac") or "UNUSED_PRESERVE" in c
+                                    or (o.endswith("_f16") and not o.startswith("v_pk_") and not o.startswith("v_cvt_pk"))):
+                        reads |= _regs(t[0])     # read-modify-write destinations (16-bit results keep the other half)
+                    if dst & reads and (sel or not _is_trans(o)):
+                        what = "a destination-select write" if sel else "a transcendental"
+                        bad.append(f"`{c}` reads the result of `{code}` ({what}) {w} wait states behind it (needs {FORWARD_WAIT})")
+                        stack.clear()
+                        break
+                if o == "s_endpgm":
+                    break
+                m = re.search(r"(\.LBB\d+_\d+)", c) if o.startswith("s_cbranch") or o == "s_branch" else None
+                if m and m.group(1) in label_at:
+                    stack.append((label_at[m.group(1)], w + 1))
+                    if o == "s_branch":
+                        break
+                w += int(t[0], 0) + 1 if (o == "s_nop" and t) else 1
+                j += 1
+    return n_sel, bad
+
+
+def check_file_forwarding(path: str, fragment: str = "flow_kernel") -> Dict[str, Tuple[int, List[str]]]:
+    lines = open(path).read().splitlines()
+    return {k: check_forwarding_hazards_lines(lines, k) for k in kernel_names(lines, fragment)}

@@ -114,6 +114,11 @@ def _check_asm_mfma(asm_path: str):
     for k, (n, bad) in _asmcheck.check_file_swap(asm_path).items():
         if bad:
             out.setdefault(k, []).extend(bad)
+    # ... and the third: results of transcendentals and of destination-select writes read one instruction later (the packed-fp16
+    # sigmoids of csrc/flow32.hip are inline asm, invisible to the compiler's hazard recogniser)
+    for k, (n, bad) in _asmcheck.check_file_forwarding(asm_path).items():
+        if bad:
+            out.setdefault(k, []).extend(bad)
     return out
 
 

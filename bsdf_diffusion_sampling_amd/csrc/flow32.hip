@@ -131,6 +131,43 @@ __device__ __forceinline__ void act16(const f32x16& z, float (&hs)[16], float (&
     }
 }
 
+// ---- precision f16 (single fp16 products, samples only): the sigmoids in PACKED fp16 ----
+// A transcendental of both halves of four packed-fp16 registers: the low halves by the plain 16-bit form (gfx9 keeps the
+// destination's high half), the high halves by SDWA word selects (the compiler converts, evaluates and re-packs value by value:
+// v_cvt_f16_f32 + v_pack_b32_f16, ~1.3x the VALU).  Every result is written >= 3 instructions before it is touched again and one
+// wait state separates the block from its consumers: a VALU reading a transcendental's or a dst_sel write's result needs one on
+// gfx940-class parts, and the compiler's hazard recogniser does not look inside an asm statement.
+#define BSDFD_PK4_TRANS(OP, R, X)                                                                                             \
+    asm(OP "_e32 %0, %4\n\t" OP "_e32 %1, %5\n\t" OP "_e32 %2, %6\n\t" OP "_e32 %3, %7\n\t"                                \
+        OP "_sdwa %0, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                                       \
+        OP "_sdwa %1, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                                       \
+        OP "_sdwa %2, %6 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                                       \
+        OP "_sdwa %3, %7 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\ts_nop 0"                                \
+        : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3]) : "v"(X[0]), "v"(X[1]), "v"(X[2]), "v"(X[3]))
+// eight scaled pre-activations (fp32 accumulators) -> the B fragment of one K = 16 chunk: hs = zs / (1 + 2^zs) evaluated on the
+// pre-activation rounded to fp16.  3 plain VALU + 4 transcendentals per pair of units against 4.5 + 4 in fp32; the error is that
+// of the fp16 operand the MFMA takes anyway (|x - oracle| p99 3.6e-3 either way on the 64 x 6 teacher at T = 128, contract 2e-2).
+// Overflow: 2^zs = inf from zs = 16 -> sigma = 0, hs = 0 (the limit); no 0 x inf (zs is finite in fp16 for |z| < 4.5e4).
+__device__ __forceinline__ void act_pack8(const float (&zs)[8], Frag& b) {
+    f16x2 zh[4], e[4], a[4], sg[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) zh[k] = (f16x2){(_Float16)zs[2 * k], (_Float16)zs[2 * k + 1]};
+    BSDFD_PK4_TRANS("v_exp_f16", e, zh);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = e[k] + (f16x2){(_Float16)1.0f, (_Float16)1.0f};
+    BSDFD_PK4_TRANS("v_rcp_f16", sg, a);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b.p[k] = zh[k] * sg[k];
+}
+// a 32-wide layer (the lane's 16 units) -> the hi fragments of split16's layout
+__device__ __forceinline__ void act_pack16(const f32x16& z, Frag (&hi)[2]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float z8[8] = {z[8 * c], z[8 * c + 1], z[8 * c + 2], z[8 * c + 3], z[8 * c + 4], z[8 * c + 5], z[8 * c + 6], z[8 * c + 7]};
+        act_pack8(z8, hi[c]);
+    }
+}
+
 // one 32 x 32 matrix = 4 fragments (hi chunk 0, hi chunk 1, lo chunk 0, lo chunk 1)
 struct Mat32 {
     f16x8 h0, h1, l0, l1;
@@ -533,17 +570,16 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
             };
             if (!SPH) {
                 // ---- MIM, disk 25-32-32-32-2: U_i = F_i g1, R_j = G_j g3, J_ji = sum_k R_j[k] g2[k] U_i[k] (bsdfd.hip, block MIM)
-                act16<JAC>(z, hv, gv);
-                split16<SPLIT>(hv, bh, bl);
+                if constexpr (SPLIT) { act16<JAC>(z, hv, gv); split16(hv, bh, bl); }
+                else act_pack16(z, bh);
                 z = mm6<SPLIT>(load_mat(smem, LY::WH, lane), bh, bl);
                 if constexpr (JAC) {
                     split16(gv, gh, gl);
                     mm6x2(load_mat(smem, LY::WF, lane), gh, gl, load_mat(smem, LY::WF + 4 * FR32, lane), gh, gl, U0, U1);
                 }
                 // hidden layer 2 (its silu' stays in fp32)
-                act16<JAC>(z, hv, gm);
-                if constexpr (JAC) premul();
-                split16<SPLIT>(hv, bh, bl);
+                if constexpr (SPLIT) { act16<JAC>(z, hv, gm); if constexpr (JAC) premul(); split16(hv, bh, bl); }
+                else act_pack16(z, bh);
                 z = mm6<SPLIT>(load_mat(smem, LY::WH + 4 * FR32, lane), bh, bl);
             } else {
                 // ---- MIMS, spherical 26-32-32-32-32-2: two forward-mode tangent layers, then the output fold (bsdfd.hip, block MIMS)
@@ -565,8 +601,8 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
                 }
 #pragma unroll
                 for (int layer = 0; layer < 2; ++layer) {
-                    act16<JAC>(z, hv, gv);
-                    split16<SPLIT>(hv, bh, bl);
+                    if constexpr (SPLIT) { act16<JAC>(z, hv, gv); split16(hv, bh, bl); }
+                    else act_pack16(z, bh);
                     const Mat32 w = load_mat(smem, LY::WH + layer * 4 * FR32, lane);
                     z = mm6<SPLIT>(w, bh, bl);
                     if constexpr (JAC) {
@@ -584,9 +620,8 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
                 }
                 if constexpr (JAC) { U0 = zt0; U1 = zt1; }
                 // hidden layer 3 (its silu' stays in fp32)
-                act16<JAC>(z, hv, gm);
-                if constexpr (JAC) premul();
-                split16<SPLIT>(hv, bh, bl);
+                if constexpr (SPLIT) { act16<JAC>(z, hv, gm); if constexpr (JAC) premul(); split16(hv, bh, bl); }
+                else act_pack16(z, bh);
                 z = mm6<SPLIT>(load_mat(smem, LY::WH + 2 * 4 * FR32, lane), bh, bl);
             }
             // ---- last hidden layer -> R0, R1 (MFMA), v (fp32 VALU dot over the lane's 16 units + one swap) ----
@@ -905,14 +940,17 @@ __global__ __launch_bounds__(512, 4) void flow_kernel32w(const KParams p) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) hv[mt][v] = z[mt][v] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[mt][v]));
+                    for (int v = 0; v < 16; ++v)   // the last layer feeds the fp32 output dot: fp32 sigmoids
+                        if (layer == LY::NH - 1) hv[mt][v] = z[mt][v] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z[mt][v]));
                 if (layer == LY::NH - 1) break;
-                Frag fr[4];
+                Frag fr[4];   // every other layer: packed-fp16 sigmoids straight into the B fragments (act_pack8)
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+                for (int c = 0; c < 4; ++c) {
+                    float z8[8];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        fr[c].p[k] = (f16x2){(_Float16)hv[c >> 1][8 * (c & 1) + 2 * k], (_Float16)hv[c >> 1][8 * (c & 1) + 2 * k + 1]};
+                    for (int k = 0; k < 8; ++k) z8[k] = z[c >> 1][8 * (c & 1) + k];
+                    act_pack8(z8, fr[c]);
+                }
                 const f16x8* W = reinterpret_cast<const f16x8*>(smem + LY::WH + layer * 8 * FR32) + lane;
 #pragma unroll
                 for (int mo = 0; mo < 2; ++mo) {

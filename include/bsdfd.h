@@ -44,7 +44,8 @@ extern "C" {
                                * Range: hidden activations and tangents must stay below fp16's 65504 (they are
                                * O(1..100) for the reference's nets and inputs); beyond it the result is inf/NaN,
                                * never a silently wrong finite number. BSDFD_PREC_F32 has fp32 range. */
-#define BSDFD_PREC_F16 3      /* single fp16 MFMA pass (tcnn-class 1e-2 tolerance; reflow teacher sampling) */
+#define BSDFD_PREC_F16 3      /* single fp16 MFMA pass (tcnn-class 1e-2 tolerance; reflow teacher sampling); the 32-query-tile
+                               * kernels of bsdfd_flow_samples_only also evaluate the hidden layers' sigmoids in fp16 */
 
 /* Plugin post-processing variants (which MyBSDF the call mirrors). */
 #define BSDFD_PLUGIN_MEASURED 0    /* rendering/brdf_measured_{disk,spherical}.py */

@@ -483,7 +483,8 @@ def test_assembly_census_fails_closed(tmp_path):
     assert A.verify_census(paths, "async") == []
     exp = A.expected_flow_kernels("async")
     assert len(exp) == 63 and sum(1 for v in exp.values() if v["async"]) == 8      # 54 in csrc/bsdfd.hip + 9 in csrc/flow32.hip
-    assert all(v == {"async": 0, "waits": 0} for v in A.expected_flow_kernels("plain").values())
+    assert all((v["async"], v["waits"]) == (0, 0) for v in A.expected_flow_kernels("plain").values())
+    assert sum(1 for v in exp.values() if v.get("sel")) == 3                        # the packed-fp16 sigmoids (inline-asm SDWA halves)
     empty = tmp_path / "empty.s"
     empty.write_text("")
     assert len(A.verify_census([str(empty)], "async")) == 63                        # (a) nothing found
@@ -507,6 +508,10 @@ def test_assembly_census_fails_closed(tmp_path):
     scratch.write_text(text.replace(".private_segment_fixed_size: 0", ".private_segment_fixed_size: 68", 1))
     got = A.verify_census([str(scratch), paths[1]], "async")
     assert len(got) == 1 and "68 B of scratch" in got[0]
+    nosel = tmp_path / "nosel.s"                                                    # (d) destination selects under another spelling
+    nosel.write_text(open(paths[1]).read().replace("dst_sel:WORD_1", "dstsel:WORD_1"))
+    got = A.verify_census([paths[0], str(nosel)], "async")
+    assert len(got) == 3 and all("0 destination-select writes" in m for m in got)
     extra = tmp_path / "extra.s"
     extra.write_text(text.replace("flow_kernelILi0ELi2ELi2ELb1ELi3ELb0EE", "flow_kernelILi0ELi2ELi2ELb1ELi5ELb0EE"))
     got = A.verify_census([str(extra), paths[1]], "async")
@@ -538,6 +543,41 @@ def test_asmcheck_mfma_operands_in_agprs_and_as_matrix_inputs():
     taken = head + ("\tv_mfma_f32_16x16x4_f32 v[56:59], v1, v2, 0\n\tv_mfma_f32_16x16x4_f32 v[54:57], v3, v4, v[56:59]\n"
                     "\tv_mfma_f32_16x16x4_f32 v[54:57], v5, v6, v[54:57]\n\ts_nop 7\n\ts_nop 1\n\tv_mov_b32_e32 v0, v55\n") + tail
     assert A.check_mfma_hazards_lines(taken.splitlines(), key) == (3, [])
+
+
+def test_asmcheck_forwarding_hazards_of_transcendentals_and_destination_selects():
+    """gfx940-class forwarding hazards (LLVM checkVALUHazards): a non-transcendental VALU reading a transcendental's result, and any
+    VALU reading a register written through a destination select, must be one wait state behind it.  The packed-fp16 sigmoids of
+    csrc/flow32.hip are inline asm the compiler's hazard recogniser cannot see into: the build checks every kernel."""
+    from bsdf_diffusion_sampling_amd import _asmcheck as A
+    head, tail = "_Z3toyflow_kernelX:\n", "\ts_endpgm\n"
+    def chk(body):
+        return A.check_forwarding_hazards_lines((head + body + tail).splitlines(), "flow_kernelX")
+    n, bad = chk("\tv_exp_f32_e32 v1, v0\n\tv_add_f32_e32 v2, 1.0, v1\n")
+    assert n == 0 and len(bad) == 1 and "a transcendental" in bad[0]
+    assert chk("\tv_exp_f32_e32 v1, v0\n\ts_nop 0\n\tv_add_f32_e32 v2, 1.0, v1\n") == (0, [])
+    assert chk("\tv_exp_f32_e32 v1, v0\n\tv_mov_b32_e32 v9, v8\n\tv_add_f32_e32 v2, 1.0, v1\n") == (0, [])
+    assert chk("\tv_exp_f32_e32 v1, v0\n\tv_rcp_f32_e32 v2, v1\n") == (0, [])             # transcendental -> transcendental: exempt
+    sdwa = "\tv_exp_f16_sdwa v7, v0 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n"
+    n, bad = chk(sdwa + "\tv_rcp_f16_e32 v8, v7\n")                                       # ... but not behind a destination select
+    assert n == 1 and len(bad) == 1 and "destination-select write" in bad[0]
+    n, bad = chk(sdwa + "\tv_pk_mul_f16 v8, v7, v9\n")
+    assert n == 1 and len(bad) == 1
+    assert chk(sdwa + "\ts_nop 0\n\tv_pk_mul_f16 v8, v7, v9\n") == (1, [])
+    n, bad = chk(sdwa + sdwa.replace("WORD_1", "WORD_0"))                                  # the preserved half is a read of the destination
+    assert n == 2 and len(bad) == 1
+    # on a taken branch too
+    n, bad = chk("\tv_exp_f32_e32 v1, v0\n\ts_cbranch_scc1 .LBB0_2\n\tv_mov_b32_e32 v3, v4\n.LBB0_2:\n\tv_add_f32_e32 v2, 1.0, v1\n")
+    assert len(bad) == 0      # the branch itself is the wait state
+    n, bad = chk("\tv_exp_f32_e32 v1, v0\n\tv_readlane_b32 s0, v1, 3\n")
+    assert len(bad) == 1
+    # the shipped kernels: the packed-fp16 blocks are found, and nothing in any kernel (compiler-generated code included) is short
+    total = 0
+    for path in _product_asm():
+        for k, (n, bad) in A.check_file_forwarding(path).items():
+            assert bad == [], (k, bad[:2])
+            total += n
+    assert total == 160 + 32 + 48
 
 
 def test_build_refuses_an_unverifiable_compilation_unless_overridden(tmp_path, monkeypatch, capsys):
