@@ -969,7 +969,7 @@ def worker(a):
                               "share; measured_loop_cycles is the Euler step alone and is what the model describes.  Model = sum over "
                               "the loop's instructions of what each costs the SIMD (tools/isa_mix.py on the shipped build): in this "
                               "VALU-heavy mix MFMA time and VALU time add — a 16x16x32 MFMA 16.4 cycles, a 32x32x16 32.1, a transcendental "
-                              "~11 between plain VALU (tools/ubench/RESULTS.md rounds 3-4) — model/measured_loop ~ 1 means the step runs "
+                              "8.1 (tools/ubench/RESULTS.md; rounds 2-4 priced it at 11, round 5 measured ~7.5-8 in the kernels) — model/measured_loop ~ 1 means the step runs "
                               "at the hardware's issue rate for this instruction mix.  A tile is `tile_queries` queries (one wave64)."}
                 mdl, mdl_prov = isa_model(tile_key(a.workload, tile_q))
                 ib["model_source"] = mdl_prov

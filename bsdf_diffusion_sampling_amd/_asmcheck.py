@@ -274,6 +274,10 @@ def expected_flow_kernels(variant: str = "async") -> Dict[str, Dict[str, int]]:
                                 spec = {"async": 25 if split else 13, "waits": 5 if split else 3}
                             elif dom == 1 and nh == 4:    # block MIMS: 21 (11) reads, 5 (4) waits
                                 spec = {"async": 21 if split else 11, "waits": 5 if split else 4}
+                        if prec == _PREC_F16 and not jac:
+                            # packed-fp16 sigmoids (flow_dev.h: act_pack8): 2 x 4 destination-select writes per B fragment, NM / 2
+                            # fragments per layer; the run-time-depth loop shows its body at least once
+                            spec = dict(spec, sel=max(nh, 1) * (nm // 2) * 8)
                         out[f"flow_kernelILi{dom}ELi{nm}ELi{prec}ELb{jac}ELi{nh}ELb{fused}EE"] = spec
     for dom in (0, 1):                                    # csrc/flow32.hip, compiler-managed LDS reads
         for jac, fused, split in ((0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 0, 0)):   # <DOMAIN, JAC, FUSED, SPLIT>; (0, 0, 0): precision f16, samples-only

@@ -938,6 +938,15 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
                     }
 #pragma unroll
                     for (int m = 0; m < NM; ++m) {
+                        if constexpr (!SPLIT && !JAC && PREC == BSDFD_PREC_F16) {
+                            // precision f16, no Jacobian: two M-tiles' sigmoids in packed fp16 straight into the chunk's B fragment
+                            // (flow_dev.h: act_pack8; round 5, as in the 32-query-tile kernels of csrc/flow32.hip)
+                            if ((m & 1) == 0) {
+                                const float z8[8] = {z[m][0], z[m][1], z[m][2], z[m][3], z[m + 1][0], z[m + 1][1], z[m + 1][2], z[m + 1][3]};
+                                act_pack8(z8, bh[m >> 1]);
+                            }
+                            continue;
+                        }
                         float hv[4], t0v[4], t1v[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {

@@ -484,7 +484,7 @@ def test_assembly_census_fails_closed(tmp_path):
     exp = A.expected_flow_kernels("async")
     assert len(exp) == 63 and sum(1 for v in exp.values() if v["async"]) == 8      # 54 in csrc/bsdfd.hip + 9 in csrc/flow32.hip
     assert all((v["async"], v["waits"]) == (0, 0) for v in A.expected_flow_kernels("plain").values())
-    assert sum(1 for v in exp.values() if v.get("sel")) == 3                        # the packed-fp16 sigmoids (inline-asm SDWA halves)
+    assert sum(1 for v in exp.values() if v.get("sel")) == 3 + 7                    # the packed-fp16 sigmoids (inline-asm SDWA halves)
     empty = tmp_path / "empty.s"
     empty.write_text("")
     assert len(A.verify_census([str(empty)], "async")) == 63                        # (a) nothing found
@@ -512,6 +512,9 @@ def test_assembly_census_fails_closed(tmp_path):
     nosel.write_text(open(paths[1]).read().replace("dst_sel:WORD_1", "dstsel:WORD_1"))
     got = A.verify_census([paths[0], str(nosel)], "async")
     assert len(got) == 3 and all("0 destination-select writes" in m for m in got)
+    nosel.write_text(text.replace("dst_sel:WORD_1", "dstsel:WORD_1"))
+    got = A.verify_census([str(nosel), paths[1]], "async")
+    assert len(got) == 7 and all("0 destination-select writes" in m for m in got)
     extra = tmp_path / "extra.s"
     extra.write_text(text.replace("flow_kernelILi0ELi2ELi2ELb1ELi3ELb0EE", "flow_kernelILi0ELi2ELi2ELb1ELi5ELb0EE"))
     got = A.verify_census([str(extra), paths[1]], "async")
@@ -577,7 +580,7 @@ def test_asmcheck_forwarding_hazards_of_transcendentals_and_destination_selects(
         for k, (n, bad) in A.check_file_forwarding(path).items():
             assert bad == [], (k, bad[:2])
             total += n
-    assert total == 160 + 32 + 48
+    assert total == (160 + 32 + 48) + (24 + 16 + 32 + 32 + 16 + 96 + 32)     # csrc/flow32.hip + the 7 f16 samples-only kernels of csrc/bsdfd.hip
 
 
 def test_build_refuses_an_unverifiable_compilation_unless_overridden(tmp_path, monkeypatch, capsys):

@@ -21,11 +21,15 @@ import sys
 # inline 0), the order of dependent MFMAs, or the number of co-resident waves; only up to ~2 plain VALU per MFMA hide in an
 # MFMA-bound stream.  (Round 3 had priced an MFMA at the 9.6 cycles SQ_ACTIVE_INST_VALU attributes to it; that counter counts
 # issue events in quad-cycle granules, not occupancy: it reads 97 % on a stream that is saturated by construction and would
-# read 167 % on pure v_fma.)  VALU classes: plain VOP3 2.56, VOP2 2.14, packed-f32 / converting 4.29, a transcendental 8.1 in
-# a pure stream but ~11 between plain instructions (tools/ubench/bank).
+# read 167 % on pure v_fma.)  VALU classes: plain VOP3 2.56, VOP2 2.14, packed-f32 / converting 4.29, a transcendental 8.1 (its
+# rate in a pure stream, tools/ubench/valu_rates2).  Rounds 2-4 priced it at the ~11 a micro-benchmark read between plain
+# instructions (tools/ubench/bank); round 5 measured it IN the kernels three ways — all 97 of the disk step replaced by one
+# plain instruction each: -14 % cycles = 7.4 apiece (profiles/r05_ab/energy_ablate.jsonl); 24 v_rcp_f32 traded for 47 plain
+# instructions: +3 % time where 11 predicted -3 % (ab32_rcp_pairs.txt); the teacher's step, 384 of them, 5 240 cycles measured
+# against 6 715 by addition at 11 — and with 8.1 every kernel's measured step is within 8 % of its sum.
 COST = {"v_mfma_f32_16x16x32_f16": 16.35, "v_mfma_f32_16x16x4_f32": 32.0, "v_mfma_f32_32x32x16_f16": 32.1,
-        "v_exp_f32": 11.0, "v_rcp_f32": 11.0, "v_log_f32": 11.0, "v_sqrt_f32": 11.0, "v_sin_f32": 11.0, "v_cos_f32": 11.0,
-        "v_rsq_f32": 11.0, "v_exp_f16": 11.0, "v_rcp_f16": 11.0,
+        "v_exp_f32": 8.1, "v_rcp_f32": 8.1, "v_log_f32": 8.1, "v_sqrt_f32": 8.1, "v_sin_f32": 8.1, "v_cos_f32": 8.1,
+        "v_rsq_f32": 8.1, "v_exp_f16": 8.1, "v_rcp_f16": 8.1,
         "v_cvt_pk_f16_f32": 4.29, "v_cvt_pkrtz_f16_f32": 4.4, "v_perm_b32": 4.3, "v_cvt_f32_f16": 4.2,
         "v_fma_mix_f32": 7.3, "v_fma_mixlo_f16": 7.3, "v_fma_mixhi_f16": 7.3,
         "v_mul_f32": 2.14, "v_add_f32": 2.14, "v_sub_f32": 2.14, "v_permlane32_swap_b32": 8.2, "v_permlane16_swap_b32": 8.2}
