@@ -70,6 +70,25 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
         assert "gfx950" in out.stdout
 
 
+def test_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/bsdfd.h compiles as strict C99 (what cgo / JNI / a ctypes generator would parse)
+    and as C++11, warnings as errors, with nothing but the standard headers it includes itself."""
+    import shutil
+    if not shutil.which("gcc") or not shutil.which("g++"):
+        pytest.skip("needs gcc and g++")
+    inc = os.path.join(ROOT, "include")
+    c = tmp_path / "hdr.c"
+    c.write_text('#include "bsdfd.h"\nint main(void) { bsdfd_desc d; bsdfd_opts o; (void)d; (void)o; return BSDFD_OK; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-Wno-unused-but-set-variable", "-I", inc,
+                        "-c", str(c), "-o", str(tmp_path / "hdr_c.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cpp = tmp_path / "hdr.cpp"
+    cpp.write_text('#include "bsdfd.h"\nint main() { bsdfd_desc d{}; (void)d; return BSDFD_OK; }\n')
+    r = subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-c", str(cpp), "-o",
+                        str(tmp_path / "hdr_cpp.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly without the GPU / the HIP library."""
     if torch.cuda.is_available():
