@@ -354,7 +354,10 @@ class MixedMaterials:
         # side streams under the flow kernels of wavefront k (materials.WavefrontPipeline); every wavefront still does all
         # five stages inside the timed region ($BSDFD_BENCH_MIXED_SERIAL=1: the stages one after the other on one stream)
         from bsdf_diffusion_sampling_amd.materials import WavefrontPipeline
-        self.pipe = None if os.environ.get("BSDFD_BENCH_MIXED_SERIAL") else WavefrontPipeline(self.tab)
+        # $BSDFD_BENCH_MIXED_GATHER=1: round 4/5's form — gather of wi and scatter of the results as kernels of their own on side
+        # streams; default (round 6): the flow kernels read and write lane order through the bucket permutation (bsdfd_opts.row_index)
+        self.direct = not os.environ.get("BSDFD_BENCH_MIXED_GATHER")
+        self.pipe = None if os.environ.get("BSDFD_BENCH_MIXED_SERIAL") else WavefrontPipeline(self.tab, direct=self.direct)
         self.wave = None
         self._out = None
 
@@ -368,6 +371,10 @@ class MixedMaterials:
             self._out = None
             return
         plan = tab.bucket(self.ids)
+        if self.direct:
+            wo, pdf = tab.sample(plan, self.wi, seed=1000 + k, offset=self.rank * self.n_local, ctx=self.ctx, direct=True)
+            self._out = (wo, pdf, tab.pdf(plan, self.wi, wo, ctx=self.ctx, direct=True))
+            return
         wi_b = tab.gather(plan, self.wi)
         wo_b, pdf_b = tab.sample(plan, wi_b, seed=1000 + k, offset=self.rank * self.n_local, bucketed=True, ctx=self.ctx)
         p_b = tab.pdf(plan, wi_b, wo_b, bucketed=True, ctx=self.ctx)
@@ -391,12 +398,16 @@ class MixedMaterials:
 
     def config(self):
         return {"materials": len(self.tab), "domain": "27 disk + 25 spherical", "euler_steps": "4 (disk) / 8 (spherical)",
-                "api": "MaterialTable: bucket-by-material (native counting sort), one gather of wi, segmented plugin "
-                       "sample()/pdf() launches on the bucket-ordered arrays, one scatter of (wo, pdf, pdf) back to lane order "
-                       "— all inside the step", "per_query_context": self.ctx is not None,
-                "pipelined": self.pipe is not None,
-                "pipelining": "bucket + gather of wavefront k+1 and scatter of wavefront k-1 on side streams under the flow "
-                              "kernels of wavefront k (materials.WavefrontPipeline)" if self.pipe is not None else "none"}
+                "api": ("MaterialTable: bucket-by-material (native counting sort), segmented plugin sample()/pdf() launches that read wi "
+                        "and write (wo, pdf, pdf) in lane order THROUGH the bucket permutation (bsdfd_opts.row_index) — all inside the step"
+                        if self.direct else
+                        "MaterialTable: bucket-by-material (native counting sort), one gather of wi, segmented plugin "
+                        "sample()/pdf() launches on the bucket-ordered arrays, one scatter of (wo, pdf, pdf) back to lane order "
+                        "— all inside the step"), "per_query_context": self.ctx is not None,
+                "row_index": self.direct, "pipelined": self.pipe is not None,
+                "pipelining": ("bucketing of wavefront k+1 on a side stream under the flow kernels of wavefront k" if self.direct else
+                               "bucket + gather of wavefront k+1 and scatter of wavefront k-1 on side streams under the flow "
+                               "kernels of wavefront k") + " (materials.WavefrontPipeline)" if self.pipe is not None else "none"}
 
 
 class Teacher:
@@ -581,49 +592,30 @@ def run_secondary(name, device, precision):
             out["issue_bound"] = secondary_issue_bound(name, wl)
         except Exception as exc:   # a side figure never breaks the line
             out["issue_bound"] = {"error": repr(exc)}
+    try:
+        out["board"] = board_energy(wl, seconds=1.0)
+        out["board"].pop("launches", None)
+    except Exception as exc:
+        out["board"] = {"error": repr(exc)}
+    out["joule_per_Mquery"], out["socket_power_w"] = out["board"].get("joule_per_Mquery"), out["board"].get("socket_power_w")
     del wl
     torch.cuda.empty_cache()
     return out
 
 
-def board_power_probe(wl, seconds=1.5):
-    """rocm-smi socket power / sclk (median of the samples) while the workload's sample launch runs back to back for `seconds`;
-    values are null where rocm-smi is absent or prints another schema."""
-    import threading
+def board_energy(wl, seconds=1.5):
+    """Energy of a workload, outside the timed region (bsdf_diffusion_sampling_amd/power.py): its passes — the same sample() + pdf()
+    launches `value` is made of — run back to back for `seconds` while the board's socket power and shader clock are polled (sysfs
+    hwmon every 20 ms; rocm-smi where that is absent).  joule_per_Mquery = median W x elapsed s / (queries / 1e6): the flow kernels
+    sit at the board's power limit, so THIS is what an optimisation has to lower — time follows it."""
     import torch
-    samples, stop = [], threading.Event()
-
-    def poll():
-        while not stop.is_set():
-            try:
-                r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=15)
-                d = next(iter(json.loads(r.stdout).values()))
-                w = next((float(v) for k, v in d.items() if "Power" in k and "(W)" in k), None)
-                mhz = next((float("".join(c for c in v if c.isdigit() or c == ".")) for k, v in d.items() if k.startswith("sclk clock speed")), None)
-                samples.append((w, mhz))
-            except Exception:
-                pass
-            stop.wait(0.3)
-    launches = 0
-    for _ in range(20):
-        wl.loop_probe(wl.T)
-    torch.cuda.synchronize()
-    th = threading.Thread(target=poll, daemon=True)
-    th.start()
-    t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        for _ in range(20):
-            wl.loop_probe(wl.T)
-        launches += 20
-        torch.cuda.synchronize()
-    stop.set()
-    th.join(timeout=20)
-    ws = sorted(w for w, _ in samples if w is not None)
-    cs = sorted(c for _, c in samples if c is not None)
-    return {"socket_power_w": ws[len(ws) // 2] if ws else None, "sclk_mhz": cs[len(cs) // 2] if cs else None, "samples": len(samples),
-            "launches": launches + 20,
-            "basis": f"rocm-smi polled every 0.3 s during {seconds} s of back-to-back sample launches of the judged workload, behind the "
-                     "timed region; MI355X board limit 1 400 W, boost clock 2 400 MHz"}
+    from bsdf_diffusion_sampling_amd.power import energy_probe
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
+    res = energy_probe(wl.run_pass, wl.n_local, seconds=seconds, sync=torch.cuda.synchronize, pci_bus_id=getattr(props, "pci_bus_id", None))
+    res["launches"] = (res["calls"] + 4) * wl.launches_per_pass
+    res["basis"] = (f"passes of the workload back to back for {seconds} s behind the timed region; socket power = median of the polled "
+                    "samples; MI355X board limit 1 400 W, boost clock 2 400 MHz")
+    return res
 
 
 def secondary_issue_bound(name, wl):
@@ -759,12 +751,20 @@ def worker(a):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         R = int(t.item())
 
-    gather_out = ([torch.empty((n_local, 4), dtype=torch.float32, device=stage) for _ in range(world)]
-                  if (multi and rank == 0) else None)
+    # root's gather buffers (world x [n_local, 4] floats: 2 GiB for mixed_16Mi at 8 ranks) are allocated on FIRST USE — a run with
+    # --gather none never pays for them
+    gather_buf = []
     comm = torch.cuda.Stream(device) if multi else None
 
+    def gather_dst():
+        if rank != 0:
+            return None
+        if not gather_buf:
+            gather_buf.extend(torch.empty((n_local, 4), dtype=torch.float32, device=stage) for _ in range(world))
+        return gather_buf
+
     def gather_now():
-        dist.gather(wl.result().to(stage), gather_out, dst=0)
+        dist.gather(wl.result().to(stage), gather_dst(), dst=0)
 
     def region(mode, first_pass):
         """K steps of R passes; mode: 'final' (one gather of the last wavefront's results inside the region), 'none',
@@ -781,7 +781,7 @@ def worker(a):
                 ev.record()
                 with torch.cuda.stream(comm):
                     comm.wait_event(ev)
-                    dist.gather(res.to(stage), gather_out, dst=0)
+                    dist.gather(res.to(stage), gather_dst(), dst=0)
                     res.record_stream(comm)
                 pending = True
         if mode == "final":
@@ -988,10 +988,12 @@ def worker(a):
             # power-limited — socket power at the limit, shader clock below boost
             if rank == 0 and world == 1:
                 try:
-                    roof["board"] = board_power_probe(wl)
+                    roof["board"] = board_energy(wl)
                     roof["flow_launches_after_timed_region"] += roof["board"].pop("launches", 0)
                 except Exception as exc:
                     roof["board"] = {"error": repr(exc)}
+                roof["joule_per_Mquery"] = roof["board"].get("joule_per_Mquery")
+                roof["socket_power_w"] = roof["board"].get("socket_power_w")
         out["roofline"] = roof
         if world == 1 and not a.no_secondary:
             sec = {}

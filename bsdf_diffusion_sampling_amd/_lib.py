@@ -40,8 +40,9 @@ EXPORTS = (
     "bsdfd_measured_create_from_file", "bsdfd_measured_destroy", "bsdfd_measured_get_info", "bsdfd_measured_eval",
     "bsdfd_measured_sample_weight",
     "bsdfd_set_profiling", "bsdfd_profile_read", "bsdfd_profile_read_op", "bsdfd_profile_clock_mhz", "bsdfd_last_kernel_ms", "bsdfd_shader_clock_mhz",
-    "bsdfd_last_error", "bsdfd_version",
+    "bsdfd_last_error", "bsdfd_version", "bsdfd_abi_version",
 )
+ABI_VERSION = 6   # BSDFD_ABI_VERSION of include/bsdfd.h these ctypes structs mirror (checked against the library in lib())
 
 
 class WfScene(C.Structure):
@@ -57,15 +58,16 @@ class WfScene(C.Structure):
 
 class Opts(C.Structure):
     """bsdfd_opts (include/bsdfd.h): optional arguments of the plugin-level *_ex calls."""
-    _fields_ = [("ctx_out", C.c_void_p), ("ctx_in", C.c_void_p), ("rng_index", C.c_void_p)]
+    _fields_ = [("ctx_out", C.c_void_p), ("ctx_in", C.c_void_p), ("rng_index", C.c_void_p), ("row_index", C.c_void_p)]
 
 
-def opts(ctx_out=None, ctx_in=None, rng_index=None, byte_offset_rng: int = 0):
-    """A bsdfd_opts from torch tensors (None = absent); ``byte_offset_rng`` advances the rng_index pointer."""
+def opts(ctx_out=None, ctx_in=None, rng_index=None, byte_offset_rng: int = 0, row_index=None, byte_offset_row: int = 0):
+    """A bsdfd_opts from torch tensors (None = absent); ``byte_offset_rng`` / ``byte_offset_row`` advance the index pointers."""
     o = Opts()
     o.ctx_out = None if ctx_out is None else ctx_out.data_ptr()
     o.ctx_in = None if ctx_in is None else ctx_in.data_ptr()
     o.rng_index = None if rng_index is None else rng_index.data_ptr() + byte_offset_rng
+    o.row_index = None if row_index is None else row_index.data_ptr() + byte_offset_row
     return o
 
 
@@ -366,6 +368,10 @@ def lib():
     L.bsdfd_version.restype = C.c_char_p
     for name in EXPORTS:
         getattr(L, name)  # AttributeError if a declared symbol is missing
+    L.bsdfd_abi_version.restype = i32
+    if L.bsdfd_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} implements ABI {L.bsdfd_abi_version()} of include/bsdfd.h, this host was written for "
+                           f"{ABI_VERSION}: rebuild the library (__graft_entry__.build())")
     _lib = L
     return L
 

@@ -131,7 +131,10 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
     // spherical nets would gain 0.5 % and lose margin (golden chm_orange pdf p99 5.1e-5 -> 8.2e-5 of the 1e-4 contract): they
     // keep the exact-fp32 chains, as does every kernel in precision mode f32.
     // (the samples-only split3 kernel follows, so that it walks exactly the trajectory of the sampling kernel)
-    constexpr bool SPLIT_PRO = PREC == BSDFD_PREC_SPLIT3 && DOMAIN == BSDFD_DOMAIN_DISK;
+#ifndef BSDFD_SPLIT_PRO
+#define BSDFD_SPLIT_PRO 1   // (A/B knob of tools/ab_build.sh; 0: the exact-fp32 chains everywhere)
+#endif
+    constexpr bool SPLIT_PRO = BSDFD_SPLIT_PRO && PREC == BSDFD_PREC_SPLIT3 && DOMAIN == BSDFD_DOMAIN_DISK;
     const int n_hidden = NH ? NH : p.n_hidden;
     const int lane_k = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -208,6 +211,9 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
         };
         bool valid;
         const long long qi = row_of(q, valid);
+        // row of the callers' arrays (bsdfd_opts.row_index; flow_dev.h, KParams) — re-read in the epilogue, not carried across the loop
+        auto user_row = [&](long long r) -> long long { return p.row_index ? p.row_index[r] : r; };
+        const long long qu = user_row(qi);
 
         // ---------------- inputs: condition (y0,y1) and, for pdf, the outgoing point -------------
         float y0 = 0.f, y1 = 0.f, wi_z = 1.0f;
@@ -245,13 +251,13 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
                 xs0 = b2.x; xs1 = b2.y;
             }
         } else {
-            const float wx = p.in_a[qi * 3 + 0], wy = p.in_a[qi * 3 + 1], wz = p.in_a[qi * 3 + 2];
+            const float wx = p.in_a[qu * 3 + 0], wy = p.in_a[qu * 3 + 1], wz = p.in_a[qu * 3 + 2];
             wi_z = wz;
             if (DOMAIN == BSDFD_DOMAIN_DISK) {
                 y0 = wx; y1 = wy;  // rendering/brdf_measured_disk.py:66-67
             }
             const bool need_o = !FUSED && p.op == OP_PDF;
-            if (need_o) load_dir(p.in_b, qi);  // (the fused kernel loads wl at its phase switch: 4 registers less across phase 1)
+            if (need_o) load_dir(p.in_b, qu);  // (the fused kernel loads wl at its phase switch: 4 registers less across phase 1)
             if (DOMAIN == BSDFD_DOMAIN_SPHERICAL) {  // cart_to_spher, rendering/brdf_measured_spherical.py:35-39 (wave-uniform branches)
                 if (!have_ctx && need_o) {           // pdf(): four angles, one per lane of the query
                     const SphArgs ai = spher_args(wx, wy, wz);
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
                 }
             }
             if ((FUSED || p.op != OP_PDF) && p.in_b != nullptr) {  // injected base sample
-                const float2 b2 = reinterpret_cast<const float2*>(p.in_b)[qi];
+                const float2 b2 = reinterpret_cast<const float2*>(p.in_b)[qu];
                 if (FUSED) { xi0 = b2.x; xi1 = b2.y; } else { xs0 = b2.x; xs1 = b2.y; }
             }
         }
@@ -388,12 +394,12 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
         // ---------------- initial state ------------------------------------------------------------
         if (FUSED && ph) {
             bool v2;
-            load_dir(p.in_c, REMAT ? row_of(opaque(q), v2) : qi);
+            load_dir(p.in_c, user_row(REMAT ? row_of(opaque(q), v2) : qi));
             if (DOMAIN == BSDFD_DOMAIN_SPHERICAL) angles_of(ao, xs0, xs1);
         }
         float x0 = (FUSED && !ph) ? xi0 : xs0, x1 = (FUSED && !ph) ? xi1 : xs1;
         if (op == OP_SAMPLE && p.in_b == nullptr) {  // draw x0 ~ D_base(. | omega_i) in-kernel
-            const unsigned long long ctr = p.offset + (unsigned long long)(p.rng_index ? p.rng_index[qi] : qi);
+            const unsigned long long ctr = p.offset + (unsigned long long)(p.rng_index ? p.rng_index[qi] : qu);
             const unsigned k0 = (unsigned)p.seed, k1 = (unsigned)(p.seed >> 32);
             unsigned u[4];
             philox4x32(k0, k1, (unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0x476175u, u);  // "Gau"
@@ -1110,7 +1116,8 @@ __global__ __launch_bounds__(NM == 2 ? 256 : 512, BSDFD_MIN_WAVES) void flow_ker
         else if (op == OP_PDF) pdf = base_pdf(x0, x1) * acc;
 
         bool valid_e = valid;
-        const long long qe = REMAT ? row_of(opaque(q), valid_e) : qi;
+        const long long qe_tile = REMAT ? row_of(opaque(q), valid_e) : qi;
+        const long long qe = p.io == IO_OPERATOR ? qe_tile : user_row(qe_tile);
         const bool writer = valid_e && g == 0;
         if (p.io == IO_OPERATOR) {
             if (writer) {
@@ -1486,12 +1493,14 @@ struct CtxArg {  // optional arguments of a call (bsdfd_opts) and the bucket num
     const float* in = nullptr;
     int seg_base = 0;
     const long long* rng_index = nullptr;
+    const long long* row_index = nullptr;
     CtxArg() = default;
     explicit CtxArg(const bsdfd_opts* o) {
         if (!o) return;
         out = static_cast<float*>(o->ctx_out);
         in = static_cast<const float*>(o->ctx_in);
         rng_index = reinterpret_cast<const long long*>(o->rng_index);
+        row_index = reinterpret_cast<const long long*>(o->row_index);
     }
 };
 
@@ -1517,6 +1526,8 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
         return fail(BSDFD_EINVAL, "a call either writes a per-query context (ctx_out) or reads one (ctx_in), not both");
     if (ctx.rng_index && (op == OP_PDF || op == OP_SAMPLES_ONLY))
         return fail(BSDFD_EINVAL, "rng_index applies to calls that draw base samples (sample, sample_pdf)");
+    if (ctx.row_index && io == IO_OPERATOR)
+        return fail(BSDFD_EINVAL, "row_index applies to the plugin-level calls (sample, pdf, sample_pdf)");
     if ((reinterpret_cast<uintptr_t>(ctx.out) | reinterpret_cast<uintptr_t>(ctx.in)) & 15u)
         return fail(BSDFD_EINVAL, "the per-query context buffer must be 16-byte aligned");
     int dev = -1;
@@ -1531,9 +1542,14 @@ int run(bsdfd_handle h, int op, int io, const float* in_a, const float* in_b, ui
     kp.nseg = 0;
     kp.chunk_log2 = 3;
     kp.ctx_out = ctx.out; kp.ctx_in = ctx.in; kp.seg_base = ctx.seg_base; kp.rng_index = ctx.rng_index;
+    kp.row_index = ctx.row_index;
     kp.clk = nullptr;
 
     const int mode = op == OP_SAMPLES_ONLY ? 0 : (op == OP_SAMPLE_PDF ? 2 : 1);
+    // flow_kernel32w (the 64 x 6 f16 samples-only kernel, mode 0) reads neither segments, nor a context, nor rng_index / row_index:
+    // all four are rejected for OP_SAMPLES_ONLY above and below — keep it that way if that validation is ever relaxed
+    if (mode == 0 && (segs || ctx.out || ctx.in || ctx.rng_index || ctx.row_index))
+        return fail(BSDFD_EINVAL, "flow_samples_only takes no segments, per-query context, rng_index or row_index");
     const int threads = h->threads[mode];
     const int waves = threads / 64;
     // grid: 4 rounds of the resident capacity (blocks per CU from the occupancy query of the
@@ -1670,6 +1686,10 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     int prec = d->precision == BSDFD_PREC_DEFAULT ? BSDFD_PREC_SPLIT3 : d->precision;
     if (prec != BSDFD_PREC_F32 && prec != BSDFD_PREC_SPLIT3 && prec != BSDFD_PREC_F16)
         return fail(BSDFD_EINVAL, "unknown precision");
+    if (d->tile == 32 && !bsdfd_tile32_supported(*d, prec))
+        return fail(BSDFD_EINVAL, "tile = 32 was asked for explicitly, but no 32-query-tile kernel exists for this net and precision "
+                                  "(they serve the disk 32x3 / spherical 32x4 nets in split3 and f16 and the spherical 64x6 net in f16); "
+                                  "pass 0 for the library's default or 16");
     int dev = -1;
     HIP_TRY(hipGetDevice(&dev));
     hipDeviceProp_t prop;
@@ -1700,14 +1720,11 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     }
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->d_img), img.size());
     if (e == hipSuccess) e = hipMemcpy(h->d_img, img.data(), img.size(), hipMemcpyHostToDevice);
-    // Tile of the Jacobian kernels: desc->tile (0 = the library's default, which $BSDFD_TILE overrides: A/B runs of one build).
-    // The 32-query-tile kernels exist for the reference's two plugin nets in split3 only; everything else runs 16-query tiles.
-    int want_tile = d->tile;
-    if (want_tile == 0) {
-        const char* ev = std::getenv("BSDFD_TILE");   // "16" or "32"; anything else (unset, empty, a typo) leaves the default
-        const int et = ev ? std::atoi(ev) : 0;
-        want_tile = (et == 16 || et == 32) ? et : kDefaultTile;
-    }
+    // Tile: desc->tile alone decides (0 = the library's default; the library reads no environment variable — the Python hosts map
+    // $BSDFD_TILE onto the field for A/B runs of one build).  The 32-query-tile kernels exist for the reference's two plugin nets in
+    // split3 (every call) and for the samples-only call of those nets and of the 64 x 6 teacher in f16; everything else runs
+    // 16-query tiles — silently under the default, with an error when 32 was asked for explicitly and cannot be honoured at all.
+    const int want_tile = d->tile == 0 ? kDefaultTile : d->tile;
     const bool t32 = want_tile == 32 && bsdfd_tile32_supported(*d, prec);
     for (int m = 0; m < 3; ++m) {
         h->tile[m] = 16; h->img_of[m] = h->d_img; h->img_bytes[m] = h->lds_bytes[m] = h->L.total;
@@ -2026,6 +2043,7 @@ const char* bsdfd_last_error(void) { return g_err.c_str(); }
 #else
 #define BSDFD_VERIFIED_TAG ""
 #endif
-const char* bsdfd_version(void) { return "bsdfd 0.5 (gfx950; " BSDFD_LDS_VARIANT BSDFD_VERIFIED_TAG ")"; }
+const char* bsdfd_version(void) { return "bsdfd 0.6 (gfx950; " BSDFD_LDS_VARIANT BSDFD_VERIFIED_TAG ")"; }
+int32_t bsdfd_abi_version(void) { return BSDFD_ABI_VERSION; }
 
 }  // extern "C"

@@ -61,6 +61,10 @@ constexpr int FR32 = 64 * 16;  // bytes of one A fragment (32 rows x 16 K-values
 #ifndef BSDFD_T32_FUSED_SPH_WAVES
 #define BSDFD_T32_FUSED_SPH_WAVES 2   // the fused spherical sample+pdf kernel keeps more state across its two Euler loops
 #endif
+#ifndef BSDFD_T32_JAC2
+#define BSDFD_T32_JAC2 0         // A/B knob (round 6; negative, profiles/r06_ab/): the Jacobian-ONLY contractions (folded matrices, spherical
+#endif                           // tangent layers) in TWO products — 1: x rounded to fp16, no x_lo terms (and no hi/lo split of those vectors);
+                                 // 2: W_lo terms dropped.  0 = three products like the activations (the product)
 template <int DOMAIN, bool FUSED>
 struct CaccLds {
     static constexpr bool on = BSDFD_T32_CACC_LDS == 1 || (BSDFD_T32_CACC_LDS == 2 && (FUSED || DOMAIN == BSDFD_DOMAIN_SPHERICAL));
@@ -169,10 +173,18 @@ __device__ __forceinline__ void mm6x2(const Mat32& wa, const Frag (&xah)[2], con
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     a = mfma32(wa.h0, xah[0].v, zero16); b = mfma32(wb.h0, xbh[0].v, zero16);
     a = mfma32(wa.h1, xah[1].v, a); b = mfma32(wb.h1, xbh[1].v, b);
-    a = mfma32(wa.h0, xal[0].v, a); b = mfma32(wb.h0, xbl[0].v, b);
-    a = mfma32(wa.h1, xal[1].v, a); b = mfma32(wb.h1, xbl[1].v, b);
-    a = mfma32(wa.l0, xah[0].v, a); b = mfma32(wb.l0, xbh[0].v, b);
-    a = mfma32(wa.l1, xah[1].v, a); b = mfma32(wb.l1, xbh[1].v, b);
+    if (BSDFD_T32_JAC2 != 1) {
+        a = mfma32(wa.h0, xal[0].v, a); b = mfma32(wb.h0, xbl[0].v, b);
+        a = mfma32(wa.h1, xal[1].v, a); b = mfma32(wb.h1, xbl[1].v, b);
+    }
+    if (BSDFD_T32_JAC2 != 2) {
+        a = mfma32(wa.l0, xah[0].v, a); b = mfma32(wb.l0, xbh[0].v, b);
+        a = mfma32(wa.l1, xah[1].v, a); b = mfma32(wb.l1, xbh[1].v, b);
+    }
+}
+// the hi/lo split of a vector that feeds Jacobian-only contractions (BSDFD_T32_JAC2 = 1: rounded to fp16, no lo part)
+__device__ __forceinline__ void split16_jac(const float (&x)[16], Frag (&hi)[2], Frag (&lo)[2]) {
+    if (BSDFD_T32_JAC2 == 1) split16<false>(x, hi, lo); else split16<true>(x, hi, lo);
 }
 
 // Best & Fisher rejection sampler, 32-query tiles: the 2 lanes of a query test 4 consecutive proposals of the query's Philox
@@ -304,6 +316,10 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
         };
         bool in_range0;
         const long long qi = row_of(n, in_range0);
+        // row of the callers' arrays this query reads and writes (bsdfd_opts.row_index: a bucketed wavefront hands over the bucket
+        // permutation instead of gathered copies); re-read in the epilogue rather than carried across the Euler loop
+        auto user_row = [&](long long r) -> long long { return p.row_index ? p.row_index[r] : r; };
+        const long long qu = user_row(qi);
 
         // ---------------- inputs ---------------------------------------------------------------------
         // yh: this lane's coordinate of the condition omega_i (lane h encodes dimension h); xs: this lane's coordinate of the
@@ -324,6 +340,9 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
                 const SphArgs ao = spher_args(ox, oy, oz);
                 wo_pole = ao.ref_pole;
                 xs = atan2f(h ? ao.y : ao.s, h ? ao.x : ao.z);
+#ifdef BSDFD_DIAG_ACOS_AS_WRITTEN
+                if (!h) xs = ao.theta_ref;
+#endif
             }
         };
         if (p.io == IO_OPERATOR) {
@@ -335,17 +354,20 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
                 xo0 = b2.x; xo1 = b2.y;
             }
         } else {
-            const float wx = p.in_a[qi * 3 + 0], wy = p.in_a[qi * 3 + 1], wz = p.in_a[qi * 3 + 2];
+            const float wx = p.in_a[qu * 3 + 0], wy = p.in_a[qu * 3 + 1], wz = p.in_a[qu * 3 + 2];
             wi_z = wz;
             if (!SPH) {
                 yh = h ? wy : wx;  // rendering/brdf_measured_disk.py:66-67
             } else if (!have_ctx) {
                 const SphArgs ai = spher_args(wx, wy, wz);  // rendering/brdf_measured_spherical.py:35-39
                 yh = atan2f(h ? ai.y : ai.s, h ? ai.x : ai.z);
+#ifdef BSDFD_DIAG_ACOS_AS_WRITTEN
+                if (!h) yh = ai.theta_ref;
+#endif
             }
-            if (!FUSED && p.op == OP_PDF) load_dir(p.in_b, qi);
+            if (!FUSED && p.op == OP_PDF) load_dir(p.in_b, qu);
             if ((FUSED || p.op != OP_PDF) && p.in_b != nullptr) {  // injected base sample
-                const float2 b2 = reinterpret_cast<const float2*>(p.in_b)[qi];
+                const float2 b2 = reinterpret_cast<const float2*>(p.in_b)[qu];
                 if (FUSED) { xi0 = b2.x; xi1 = b2.y; } else { xs = h ? b2.y : b2.x; xo0 = b2.x; xo1 = b2.y; }
             }
         }
@@ -455,13 +477,13 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
         float* const out_pdf = (FUSED && ph) ? p.out_pdf2 : p.out_pdf;
         if (FUSED && ph) {
             bool v2;
-            load_dir(p.in_c, row_of(opaque(n), v2));
+            load_dir(p.in_c, user_row(row_of(opaque(n), v2)));
         }
         if (FUSED && !ph) { xs = h ? xi1 : xi0; xo0 = xi0; xo1 = xi1; }
         // ---------------- initial state ------------------------------------------------------------
         auto fexp = [](float x) -> float { return __builtin_amdgcn_exp2f(x * kLog2e); };
         if (op == OP_SAMPLE && p.in_b == nullptr) {  // draw x0 ~ D_base(. | omega_i): same counters and arithmetic as bsdfd.hip
-            const unsigned long long ctr = p.offset + (unsigned long long)(p.rng_index ? p.rng_index[qi] : qi);
+            const unsigned long long ctr = p.offset + (unsigned long long)(p.rng_index ? p.rng_index[qi] : qu);
             const unsigned k0 = (unsigned)p.seed, k1 = (unsigned)(p.seed >> 32);
             unsigned u[4];
             philox4x32(k0, k1, (unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0x476175u, u);  // "Gau"
@@ -515,7 +537,7 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
                 vin = h ? sp : xs;
                 win = h ? cp : alpha;
             }
-            const float vh = hi_part(vin), wh = hi_part(win);
+            const float vh = BSDFD_SPLIT_RN ? hi_part_rn(vin) : hi_part(vin), wh = BSDFD_SPLIT_RN ? hi_part_rn(win) : hi_part(win);
             const f16x2 zero2 = {(_Float16)0.0f, (_Float16)0.0f};
             const f16x2 vp = {(_Float16)vh, (_Float16)(vin - vh)}, wp = {(_Float16)wh, (_Float16)(win - wh)};
             Frag b1;
@@ -546,7 +568,7 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
                 else act_pack16(z, bh);
                 z = mm6<SPLIT>(load_mat(smem, LY::WH, lane), bh, bl);
                 if constexpr (JAC) {
-                    split16(gv, gh, gl);
+                    split16_jac(gv, gh, gl);
                     mm6x2(load_mat(smem, LY::WF, lane), gh, gl, load_mat(smem, LY::WF + 4 * FR32, lane), gh, gl, U0, U1);
                 }
                 // hidden layer 2 (its silu' stays in fp32)
@@ -585,8 +607,8 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
                             t1v[v] = zt1[v] * gv[v];
                         }
                         Frag t0h[2], t0l[2], t1h[2], t1l[2];
-                        split16(t0v, t0h, t0l);
-                        split16(t1v, t1h, t1l);
+                        split16_jac(t0v, t0h, t0l);
+                        split16_jac(t1v, t1h, t1l);
                         mm6x2(w, t0h, t0l, w, t1h, t1l, zt0, zt1);
                     }
                 }
@@ -600,7 +622,7 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
             act16<JAC>(z, hv, gv);
             f32x16 R0, R1;
             if constexpr (JAC) {
-                split16(gv, gh, gl);
+                split16_jac(gv, gh, gl);
                 mm6x2(load_mat(smem, LY::WG, lane), gh, gl, load_mat(smem, LY::WG + 4 * FR32, lane), gh, gl, R0, R1);
             }
             {
@@ -651,7 +673,8 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
         else if (op == OP_PDF) pdf = base_pdf(x0, x1) * acc;
 
         bool valid_e;
-        const long long qe = row_of(opaque(n), valid_e);
+        const long long qe_tile = row_of(opaque(n), valid_e);
+        const long long qe = p.io == IO_OPERATOR ? qe_tile : user_row(qe_tile);
         const bool writer = valid_e && h == 0;
         if (p.io == IO_OPERATOR) {
             if (writer) {

@@ -64,6 +64,11 @@ struct KParams {
     // sample: Philox counter of row i = offset + rng_index[i] (NULL: offset + i).  A bucketed wavefront passes the rows'
     // ORIGINAL lane indices, so the draws do not depend on the bucketing, the sharding or the GPU count
     const long long* rng_index;
+    // plugin io: row i of the launch reads its inputs (wi, x0, wo / wl) from row row_index[i] of the callers' arrays and writes its
+    // outputs there (NULL: row i).  A wavefront bucketed by material passes the bucket permutation: the gather of the inputs and the
+    // scatter of the results happen in the flow kernel's own loads and stores (bsdfd_opts.row_index).  The Philox counter follows
+    // (offset + row_index[i]) unless rng_index is given; segments and the per-query context stay indexed by i.
+    const long long* row_index;
     // profiling only (else NULL): every wave adds its lifetime in shader cycles (s_memtime) and in ticks of the constant-rate
     // wall clock (s_memrealtime) to one of CLK_SLOTS counter pairs (one 64-B line each: 16 Ki same-address atomics per launch
     // cost a 0.25 ms launch 6 %); the ratio of the sums is the shader clock the kernel ran at (bsdfd_profile_clock_mhz).
@@ -112,6 +117,7 @@ __device__ __forceinline__ float silu(float z) {  // base net: unscaled
 
 // hi/lo split of an fp32 value into two fp16-representable fp32 values (see header comment)
 __device__ __forceinline__ float hi_part(float x) { return __uint_as_float(__float_as_uint(x) & 0xFFFFE000u); }
+__device__ __forceinline__ float hi_part_rn(float x) { return (float)(_Float16)x; }   // (BSDFD_SPLIT_RN: the layer-1 state operands)
 
 // sin and cos of a bounded argument (|a| <~ 1e3; the encoder's arguments are 2^b y with |y| <= pi, b <= 4): Cody-Waite
 // reduction by pi/2 in four parts (8 + 11 + 11 bits + remainder: k * part is exact, so is the first subtraction) and
@@ -202,9 +208,17 @@ union Frag {  // one MFMA B fragment: the lane's 8 K-values of a chunk
     f16x8 v;
     f16x2 p[4];
 };
+#ifndef BSDFD_SPLIT_RN
+#define BSDFD_SPLIT_RN 0   // A/B knob (round 6): hi = x ROUNDED to fp16 (v_cvt_pk_f16_f32, then v_cvt_f32_f16 back) instead of truncated
+#endif
 template <bool SPLIT>
 __device__ __forceinline__ void split_pack(const float (&x)[4], f16x2& h01, f16x2& h23, f16x2& l01, f16x2& l23) {
-    if (SPLIT) {
+    if (SPLIT && BSDFD_SPLIT_RN) {
+        h01 = (f16x2){(_Float16)x[0], (_Float16)x[1]};
+        h23 = (f16x2){(_Float16)x[2], (_Float16)x[3]};
+        l01 = (f16x2){(_Float16)(x[0] - (float)h01[0]), (_Float16)(x[1] - (float)h01[1])};
+        l23 = (f16x2){(_Float16)(x[2] - (float)h23[0]), (_Float16)(x[3] - (float)h23[1])};
+    } else if (SPLIT) {
         const float h0 = hi_part(x[0]), h1 = hi_part(x[1]), h2 = hi_part(x[2]), h3 = hi_part(x[3]);
         h01 = (f16x2){(_Float16)h0, (_Float16)h1};
         h23 = (f16x2){(_Float16)h2, (_Float16)h3};
@@ -286,6 +300,9 @@ __device__ __forceinline__ float fast_acos(float x) {
 struct SphArgs {        // theta = atan2(s, z), phi = atan2(y, x)
     float s, z, y, x;
     bool ref_pole;
+#ifdef BSDFD_DIAG_ACOS_AS_WRITTEN
+    float theta_ref;    // DIAGNOSTIC BUILD ONLY (tools/acos_diag.py): acosf(z / (r + 1e-8f)), the reference's line as written in fp32
+#endif
 };
 __device__ __forceinline__ SphArgs spher_args(float x, float y, float z) {
     const float eps = 1e-8f;
@@ -295,6 +312,9 @@ __device__ __forceinline__ SphArgs spher_args(float x, float y, float z) {
     a.s = sqrtf(s2 + (2.0f * r * eps + eps * eps));
     a.z = z; a.y = y; a.x = x;
     a.ref_pole = !(fabsf(z / (r + eps)) < 1.0f);
+#ifdef BSDFD_DIAG_ACOS_AS_WRITTEN
+    a.theta_ref = acosf(z / (r + eps));
+#endif
     return a;
 }
 template <int NJ>   // NJ = 2 or 4 jobs (Y[k], X[k]); out[k] = atan2f(Y[k], X[k]) in every lane of the query

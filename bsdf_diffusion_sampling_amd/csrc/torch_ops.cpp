@@ -230,44 +230,57 @@ int64_t context_floats(int64_t h, int64_t n, int64_t n_segments) {
     return b / 4;
 }
 
+// row_index (bsdfd_opts.row_index, ABI 6): int64 [n] — the call processes n rows and reads / writes row row_index[i] of the
+// [M, .] arrays (M >= n rows; entries must be distinct and < M — not checked, they live on the device)
+const int64_t* index_ptr(const std::optional<Tensor>& t, const char* name, const at::Device& dev, int64_t n = -1) {
+    if (!t.has_value()) return nullptr;
+    const Tensor& r = *t;
+    TORCH_CHECK(r.device() == dev && r.scalar_type() == at::kLong && r.dim() == 1 && (n < 0 || r.size(0) == n) && r.is_contiguous(),
+                name, " must be a contiguous int64 tensor", n < 0 ? "" : " of the call's row count", " on ", dev);
+    return r.data_ptr<int64_t>();
+}
+
 void plugin_sample_ex_out(int64_t h, int64_t variant, const Tensor& wi, const std::optional<Tensor>& x0, int64_t seed,
                           int64_t offset, int64_t T, Tensor wo, Tensor pdf, const std::optional<Tensor>& ctx,
-                          const std::optional<Tensor>& rng_index, bool ctx_read) {
+                          const std::optional<Tensor>& rng_index, bool ctx_read, const std::optional<Tensor>& row_index) {
     const at::Device dev = wi.device();
     const float* wip = in2d(wi, 3, "wi", dev);
-    const int64_t n = wi.size(0);
-    const float* x0p = opt2d(x0, 2, "x0", dev, n);
-    in2d(wo, 3, "wo (out)", dev, n);
-    TORCH_CHECK(pdf.device() == dev && pdf.scalar_type() == at::kFloat && pdf.dim() == 1 && pdf.size(0) == n && pdf.is_contiguous(),
-                "pdf (out) must be a contiguous float32 tensor of shape [", n, "] on ", dev);
+    const int64_t m = wi.size(0);
     bsdfd_opts o{};
+    o.row_index = index_ptr(row_index, "row_index", dev);
+    const int64_t n = row_index.has_value() ? row_index->size(0) : m;
+    TORCH_CHECK(n <= m, "row_index names ", n, " rows, wi has ", m);
+    const float* x0p = opt2d(x0, 2, "x0", dev, m);
+    in2d(wo, 3, "wo (out)", dev, m);
+    TORCH_CHECK(pdf.device() == dev && pdf.scalar_type() == at::kFloat && pdf.dim() == 1 && pdf.size(0) == m && pdf.is_contiguous(),
+                "pdf (out) must be a contiguous float32 tensor of shape [", m, "] on ", dev);
     if (ctx.has_value()) {
         if (ctx_read) o.ctx_in = ctx_ptr(*ctx, h, n, dev);
         else o.ctx_out = ctx_ptr(*ctx, h, n, dev);
     }
-    if (rng_index.has_value()) {
-        const Tensor& r = *rng_index;
-        TORCH_CHECK(r.device() == dev && r.scalar_type() == at::kLong && r.dim() == 1 && r.size(0) == n && r.is_contiguous(),
-                    "rng_index must be a contiguous int64 tensor of shape [", n, "] on ", dev);
-        o.rng_index = r.data_ptr<int64_t>();
-    }
+    o.rng_index = index_ptr(rng_index, "rng_index", dev, n);
     Launch L(dev);
     ok(bsdfd_plugin_sample_ex(as_handle(h), static_cast<int32_t>(variant), wip, x0p, static_cast<uint64_t>(seed),
                               static_cast<uint64_t>(offset), n, static_cast<int32_t>(T), wo.data_ptr<float>(),
                               pdf.data_ptr<float>(), &o, L.stream));
 }
 
-void plugin_pdf_ex_out(int64_t h, int64_t variant, const Tensor& wi, const Tensor& wo, int64_t T, Tensor pdf, Tensor ctx,
-                       bool ctx_write) {
+void plugin_pdf_ex_out(int64_t h, int64_t variant, const Tensor& wi, const Tensor& wo, int64_t T, Tensor pdf,
+                       const std::optional<Tensor>& ctx, bool ctx_write, const std::optional<Tensor>& row_index) {
     const at::Device dev = wi.device();
     const float* wip = in2d(wi, 3, "wi", dev);
-    const int64_t n = wi.size(0);
-    const float* wop = in2d(wo, 3, "wo", dev, n);
-    TORCH_CHECK(pdf.device() == dev && pdf.scalar_type() == at::kFloat && pdf.dim() == 1 && pdf.size(0) == n && pdf.is_contiguous(),
-                "pdf (out) must be a contiguous float32 tensor of shape [", n, "] on ", dev);
+    const int64_t m = wi.size(0);
     bsdfd_opts o{};
-    if (ctx_write) o.ctx_out = ctx_ptr(ctx, h, n, dev);
-    else o.ctx_in = ctx_ptr(ctx, h, n, dev);
+    o.row_index = index_ptr(row_index, "row_index", dev);
+    const int64_t n = row_index.has_value() ? row_index->size(0) : m;
+    TORCH_CHECK(n <= m, "row_index names ", n, " rows, wi has ", m);
+    const float* wop = in2d(wo, 3, "wo", dev, m);
+    TORCH_CHECK(pdf.device() == dev && pdf.scalar_type() == at::kFloat && pdf.dim() == 1 && pdf.size(0) == m && pdf.is_contiguous(),
+                "pdf (out) must be a contiguous float32 tensor of shape [", m, "] on ", dev);
+    if (ctx.has_value()) {
+        if (ctx_write) o.ctx_out = ctx_ptr(*ctx, h, n, dev);
+        else o.ctx_in = ctx_ptr(*ctx, h, n, dev);
+    }
     Launch L(dev);
     ok(bsdfd_plugin_pdf_ex(as_handle(h), static_cast<int32_t>(variant), wip, wop, n, static_cast<int32_t>(T),
                            pdf.data_ptr<float>(), &o, L.stream));
@@ -293,7 +306,7 @@ TORCH_LIBRARY(bsdfd, m) {
     m.def("plugin_pdf_out(int handle, int variant, Tensor wi, Tensor wo, int T, Tensor(a!) pdf) -> ()", &plugin_pdf_out);
     m.def("context_floats(int handle, int n, int n_segments) -> int", &context_floats);
     m.def("plugin_sample_ex_out(int handle, int variant, Tensor wi, Tensor? x0, int seed, int offset, int T, Tensor(a!) wo, "
-          "Tensor(b!) pdf, Tensor(c!)? ctx, Tensor? rng_index, bool ctx_read=False) -> ()", &plugin_sample_ex_out);
-    m.def("plugin_pdf_ex_out(int handle, int variant, Tensor wi, Tensor wo, int T, Tensor(a!) pdf, Tensor(b!) ctx, bool ctx_write=False) -> ()",
-          &plugin_pdf_ex_out);
+          "Tensor(b!) pdf, Tensor(c!)? ctx, Tensor? rng_index, bool ctx_read=False, Tensor? row_index=None) -> ()", &plugin_sample_ex_out);
+    m.def("plugin_pdf_ex_out(int handle, int variant, Tensor wi, Tensor wo, int T, Tensor(a!) pdf, Tensor(b!)? ctx, bool ctx_write=False, "
+          "Tensor? row_index=None) -> ()", &plugin_pdf_ex_out);
 }

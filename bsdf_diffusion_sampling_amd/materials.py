@@ -72,8 +72,12 @@ class MaterialTable:
         return groups
 
     def _multi(self, which, members, seg_end_all, T, variant, wi_s, aux_s, seed, offset, out_wo, out_pdf, ctx=None,
-               gkey=None, rng_rows=None, ctx_fill=None):
-        """``ctx`` (a dict, or None): per-query contexts (include/bsdfd.h, bsdfd_context_bytes) of the runs of this
+               gkey=None, rng_rows=None, ctx_fill=None, direct_rows=None):
+        """``direct_rows`` (int64 [n_mat], the bucket permutation): the arrays are the CALLERS' lane-ordered ones and every launch
+        reads and writes its rows through ``bsdfd_opts.row_index`` — no gathered copy, no scatter (``direct=True`` of the public
+        calls).  The Philox counter is then ``offset + original lane`` by construction.
+
+        ``ctx`` (a dict, or None): per-query contexts (include/bsdfd.h, bsdfd_context_bytes) of the runs of this
         wavefront — the FILLING call (``ctx_fill``; default: "sample" fills, "pdf" reads) writes one buffer per (kernel
         signature, run), the other call on the same bucketed ``wi`` reads them instead of recomputing the per-query prologue.
         The dict keeps ONE buffer per (kernel signature, run number), grown to the largest wavefront seen, together with the
@@ -115,7 +119,21 @@ class MaterialTable:
                                      "ctx_fill=True) before sample(ctx=, ctx_fill=False)")
                 cbuf = ent["buf"]
             c_out, c_in = (cbuf, None) if fill else (None, cbuf)
-            if which == "sample" and (cbuf is not None or rng_rows is not None):
+            if direct_rows is not None:
+                # the row range of this run lives in the INDEX array: data pointers stay at row 0 of the lane-ordered arrays
+                o = _lib.opts(ctx_out=c_out, ctx_in=c_in, row_index=direct_rows, byte_offset_row=off_rows * 8)
+                full = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+                if which == "sample":
+                    r = L.bsdfd_plugin_sample_multi_ex(arr_h, k, arr_e, variant, full(wi_s), full(aux_s), seed, offset, T,
+                                                       full(out_wo), full(out_pdf), C.byref(o), stream)
+                elif which == "pdf":
+                    r = L.bsdfd_plugin_pdf_multi_ex(arr_h, k, arr_e, variant, full(wi_s), full(aux_s), T, full(out_pdf),
+                                                    C.byref(o), stream)
+                else:   # sample_pdf: aux_s = (x0 or None, wl), out_pdf = (pdf_wo, pdf_wl)
+                    r = L.bsdfd_plugin_sample_pdf_multi_ex(arr_h, k, arr_e, variant, full(wi_s), full(aux_s[0]), full(aux_s[1]),
+                                                           seed, offset, T, full(out_wo), full(out_pdf[0]), full(out_pdf[1]),
+                                                           C.byref(o), stream)
+            elif which == "sample" and (cbuf is not None or rng_rows is not None):
                 x0_p = None if aux_s is None else C.c_void_p(aux_s.data_ptr() + off_rows * 8)
                 # rng_rows: counter of a row = offset + its ORIGINAL lane index (not its bucketed position)
                 o = _lib.opts(ctx_out=c_out, ctx_in=c_in, rng_index=rng_rows, byte_offset_rng=off_rows * 8)
@@ -253,7 +271,8 @@ class MaterialTable:
 
     def sample(self, material_id: torch.Tensor, wi: torch.Tensor, seed: int = 0, offset: int = 0,
                T: Optional[int] = None, x0: Optional[torch.Tensor] = None, segmented: bool = True,
-               bucketed: bool = False, ctx: Optional[dict] = None, rng: str = "lane", ctx_fill: bool = True):
+               bucketed: bool = False, ctx: Optional[dict] = None, rng: str = "lane", ctx_fill: bool = True,
+               direct: bool = False):
         """wi [N,3], material_id [N] -> (wo [N,3], pdf_sa [N]) in the callers' order.
         ``rng``: ``"lane"`` (default) — the Philox counter of a query is ``offset + its ORIGINAL lane index``, so the base
         draws depend on neither the bucketing nor how the wavefront is sharded over calls / GPUs (a shard passes its
@@ -263,11 +282,34 @@ class MaterialTable:
         plan and ``wi``) to ``pdf(..., ctx=)`` and it skips the per-query prologue (identical results).  The other order
         works too: ``pdf(..., ctx=d, ctx_fill=True)`` first, then ``sample(..., ctx=d, ctx_fill=False)``.  Segmented path only.
         Identical for the segmented and the per-bucket path.  ``bucketed=True``: ``material_id`` is a
-        plan, ``wi`` / ``x0`` are already in bucket order (``gather(plan, wi)``) and the results stay in it."""
+        plan, ``wi`` / ``x0`` are already in bucket order (``gather(plan, wi)``) and the results stay in it.
+        ``direct=True``: no gathered copies at all — the launches read ``wi`` / ``x0`` and write the results in the callers' lane
+        order THROUGH the bucket permutation (``bsdfd_opts.row_index``); same results bit for bit (``rng="lane"`` only)."""
         wi = self._chk_in(wi, 3, "wi")
         x0 = self._chk_in(x0, 2, "x0", wi.shape[0])
         if ctx is not None and not segmented:
             raise ValueError("ctx= is a feature of the segmented path (segmented=False issues one plain call per bucket)")
+        if direct:
+            if bucketed or rng != "lane":
+                raise ValueError("direct=True takes lane-ordered arrays and draws with rng='lane'")
+            rows, counts, seg_end = self._plan(material_id, wi.shape[0])
+            rows = rows.contiguous()
+            mk = torch.empty if rows.shape[0] == wi.shape[0] else torch.zeros  # lanes without a material: zeros
+            wo = mk(wi.shape, dtype=torch.float32, device=wi.device)
+            pdf = mk(wi.shape[0], dtype=torch.float32, device=wi.device)
+            with torch.cuda.device(wi.device):
+                if segmented:
+                    for (dom, w, nh, prec, Tm, var), members in self._groups().items():
+                        self._multi("sample", members, seg_end, Tm if T is None else T, var, wi, x0, seed, offset, wo, pdf,
+                                    ctx=ctx, gkey=(dom, w, nh, prec, var), ctx_fill=ctx_fill, direct_rows=rows)
+                else:
+                    lo = 0
+                    for m, n in enumerate(counts):
+                        if n:
+                            self.samplers[m].plugin_sample(wi, x0, T=self.T[m] if T is None else T, variant=self.variant[m],
+                                                           seed=seed, offset=offset, out=(wo, pdf), row_index=rows[lo:lo + n])
+                        lo += n
+            return wo, pdf
         if bucketed:
             rows, counts, seg_end = self._plan_bucketed(material_id)
             if wi.shape[0] != rows.shape[0]:
@@ -311,7 +353,7 @@ class MaterialTable:
 
     def sample_pdf(self, material_id, wi: torch.Tensor, wl: torch.Tensor, seed: int = 0, offset: int = 0,
                    T: Optional[int] = None, x0: Optional[torch.Tensor] = None, return_bucketed: bool = False,
-                   rng: str = "lane"):
+                   rng: str = "lane", direct: bool = False):
         """sample(wi) and pdf(wi, wl) for the same material-tagged intersections, one launch per kernel
         signature (``bsdfd_plugin_sample_pdf_multi``) -> (wo [N,3], pdf(wo) [N], pdf(wl) [N]) in the callers' order."""
         wi = self._chk_in(wi, 3, "wi")
@@ -319,6 +361,18 @@ class MaterialTable:
         x0 = self._chk_in(x0, 2, "x0", wi.shape[0])
         rows, counts, seg_end = self._plan(material_id, wi.shape[0])  # lanes of the extra bins carry no material
         n_mat = rows.shape[0]
+        if direct:   # through the bucket permutation: no gathered copies, results land in lane order
+            if return_bucketed or rng != "lane":
+                raise ValueError("direct=True returns lane-ordered arrays only and draws with rng='lane'")
+            mk = torch.empty if n_mat == wi.shape[0] else torch.zeros
+            wo = mk(wi.shape, dtype=torch.float32, device=wi.device)
+            po = mk(wi.shape[0], dtype=torch.float32, device=wi.device)
+            pl = mk(wi.shape[0], dtype=torch.float32, device=wi.device)
+            with torch.cuda.device(wi.device):
+                for (dom, w, nh, prec, Tm, var), members in self._groups().items():
+                    self._multi("sample_pdf", members, seg_end, Tm if T is None else T, var, wi, (x0, wl), seed, offset,
+                                wo, (po, pl), direct_rows=rows.contiguous())
+            return wo, po, pl
         wi_s, wl_s = wi[rows].contiguous(), wl[rows].contiguous()
         x0_s = None if x0 is None else x0[rows].contiguous()
         wo_s = torch.empty_like(wi_s)
@@ -341,11 +395,31 @@ class MaterialTable:
         return wo, po, pl
 
     def pdf(self, material_id: torch.Tensor, wi: torch.Tensor, wo: torch.Tensor, T: Optional[int] = None,
-            segmented: bool = True, bucketed: bool = False, ctx: Optional[dict] = None, ctx_fill: bool = False):
+            segmented: bool = True, bucketed: bool = False, ctx: Optional[dict] = None, ctx_fill: bool = False,
+            direct: bool = False):
         wi = self._chk_in(wi, 3, "wi")
         wo = self._chk_in(wo, 3, "wo", wi.shape[0])
         if ctx is not None and not segmented:
             raise ValueError("ctx= is a feature of the segmented path (segmented=False issues one plain call per bucket)")
+        if direct:   # lane-ordered arrays, read and written through the bucket permutation (see sample())
+            if bucketed:
+                raise ValueError("direct=True takes lane-ordered arrays")
+            rows, counts, seg_end = self._plan(material_id, wi.shape[0])
+            rows = rows.contiguous()
+            pdf = (torch.empty if rows.shape[0] == wi.shape[0] else torch.zeros)(wi.shape[0], dtype=torch.float32, device=wi.device)
+            with torch.cuda.device(wi.device):
+                if segmented:
+                    for (dom, w, nh, prec, Tm, var), members in self._groups().items():
+                        self._multi("pdf", members, seg_end, Tm if T is None else T, var, wi, wo, 0, 0, None, pdf,
+                                    ctx=ctx, gkey=(dom, w, nh, prec, var), ctx_fill=ctx_fill, direct_rows=rows)
+                else:
+                    lo = 0
+                    for m, n in enumerate(counts):
+                        if n:
+                            self.samplers[m].plugin_pdf(wi, wo, T=self.T[m] if T is None else T, variant=self.variant[m],
+                                                        out=pdf, row_index=rows[lo:lo + n])
+                        lo += n
+            return pdf
         if bucketed:
             rows, counts, seg_end = self._plan_bucketed(material_id)
             if wi.shape[0] != rows.shape[0]:
@@ -404,8 +478,13 @@ class WavefrontPipeline:
     ``push()`` returns a ``_Wavefront``; at most two are in flight: the buffers of wavefront k are reused by wavefront k+2,
     so take ``result()`` of a wavefront before pushing the second one after it."""
 
-    def __init__(self, table: MaterialTable):
+    def __init__(self, table: MaterialTable, direct: bool = True):
+        """``direct`` (default since round 6): the flow kernels read ``wi`` and write the results in lane order through the bucket
+        permutation (``bsdfd_opts.row_index``) — only the bucketing itself (count, scan, permutation) is left on the side stream,
+        the gather of ``wi`` and the scatter of (wo, pdf, pdf) are gone.  ``direct=False``: the round-4 form (gather on the side
+        stream, bucket-ordered launches, scatter on a third stream); identical results."""
         self.tab = table
+        self.direct = direct
         self.pre = self.post = None
         self.slots = [_Wavefront(), _Wavefront()]
         self.k = 0
@@ -433,12 +512,20 @@ class WavefrontPipeline:
             if w.flow_done is not None:
                 self.pre.wait_event(w.flow_done)       # the flow kernels of wavefront k-2 have read the buffers reused here
             plan = tab.bucket(material_id, extra_bins)  # (the host waits for the counts on THIS stream only)
-            wi_b = tab.gather(plan, wi)
+            wi_b = None if self.direct else tab.gather(plan, wi)
             for t in (plan[0], wi_b):
-                t.record_stream(main)
+                if t is not None:
+                    t.record_stream(main)
             w.plan, w.wi_b = plan, wi_b
             w.prep_done = self.pre.record_event()
         main.wait_event(w.prep_done)
+        if self.direct:
+            wo, pdf = tab.sample(plan, wi, seed=seed, offset=offset, ctx=ctx, direct=True)
+            p2 = tab.pdf(plan, wi, wo, ctx=ctx, direct=True)
+            w.bucketed = None
+            w.out = (wo, pdf, p2)
+            w.flow_done = w.scatter_done = main.record_event()
+            return w
         if w.scatter_done is not None:
             main.wait_event(w.scatter_done)
         wo_b, pdf_b = tab.sample(plan, wi_b, seed=seed, offset=offset, bucketed=True, ctx=ctx)

@@ -45,7 +45,9 @@ class FlowSampler:
                  binding: Optional[str] = None, tile: int = 0):
         """``binding``: 'ctypes' or 'torch' — which host shim the per-call entry points go through (default:
         ``default_binding()``).  The handle is created through the C ABI either way and is the same object.
-        ``tile``: bsdfd_desc.tile — 0 (library default / $BSDFD_TILE), 16 or 32 queries per wave tile."""
+        ``tile``: bsdfd_desc.tile — 0 (default), 16 or 32 queries per wave tile.  With 0, ``$BSDFD_TILE=16`` selects the 16-query
+        kernels (A/B runs of one build; the LIBRARY reads no environment variable — this host maps it onto the field; "32" is the
+        default anyway wherever such a kernel exists).  An explicit 32 for a net / precision without a 32-query kernel raises."""
         if not torch.cuda.is_available():
             raise RuntimeError("FlowSampler needs an MI355X (torch.cuda is unavailable); there is no CPU path")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
@@ -59,6 +61,10 @@ class FlowSampler:
         d.base_hidden, d.base_pe_bands = fw.base_hidden, fw.base_pe_bands
         d.precision = _lib.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
         d.tile = int(tile)
+        if d.tile == 0:
+            import os
+            if os.environ.get("BSDFD_TILE", "").strip() == "16":
+                d.tile = 16
         keep = []
         for name in ("w_in", "w_hidden", "w_out", "base_w1", "base_b1", "base_w2", "base_b2"):
             a = np.ascontiguousarray(getattr(fw, name), dtype=np.float32)
@@ -230,18 +236,22 @@ class FlowSampler:
     def plugin_sample(self, wi, x0=None, T: int = 4, variant: int = _lib.PLUGIN_MEASURED, seed: int = 0,
                       offset: int = 0, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                       ctx_out: Optional[torch.Tensor] = None, rng_index: Optional[torch.Tensor] = None,
-                      ctx_in: Optional[torch.Tensor] = None):
+                      ctx_in: Optional[torch.Tensor] = None, row_index: Optional[torch.Tensor] = None):
         """``ctx_out`` (``new_context(N)``): also write the per-query context a later ``plugin_pdf(wi, ., ctx_in=)`` /
         ``plugin_sample(wi, ctx_in=)`` for the SAME ``wi`` reads instead of recomputing the prologue (identical results);
         ``ctx_in``: read the context an earlier call (``plugin_pdf(..., ctx_out=)`` or ``plugin_sample(..., ctx_out=)``) wrote
         for this very ``wi``.  At most one of the two.
         ``rng_index`` (int64 [N]): the Philox counter of row i is ``offset + rng_index[i]`` instead of ``offset + i``
-        (a bucketed wavefront passes the rows' original lane indices: draws independent of the bucketing)."""
+        (a bucketed wavefront passes the rows' original lane indices: draws independent of the bucketing).
+        ``row_index`` (int64 [n], n <= N, distinct entries < N): the call processes n rows; row i reads ``wi`` / ``x0`` at row
+        ``row_index[i]`` and writes ``wo`` / ``pdf`` there (bsdfd_opts.row_index: the gather / scatter of a bucketed wavefront
+        inside the kernel's own loads and stores); rows it does not name are left as they are (zeros when ``out`` is None).
+        Its Philox counter is ``offset + row_index[i]`` unless ``rng_index`` is given."""
         if ctx_out is not None and ctx_in is not None:
             raise RuntimeError("a call either writes a per-query context (ctx_out) or reads one (ctx_in), not both")
-        if ctx_out is not None or ctx_in is not None or rng_index is not None:
+        if ctx_out is not None or ctx_in is not None or rng_index is not None or row_index is not None:
             return self._plugin_sample_ex(wi, x0, T, variant, seed, offset, out, ctx_out if ctx_in is None else ctx_in, rng_index,
-                                          ctx_read=ctx_in is not None)
+                                          ctx_read=ctx_in is not None, row_index=row_index)
         if self._ops is not None:
             self._dev_chk(wi, "wi")
             if out is None:
@@ -261,38 +271,50 @@ class FlowSampler:
                                                    _ptr(wo), _ptr(pdf), self._stream()))
         return wo, pdf
 
-    def _chk_index(self, idx, n):
+    def _chk_index(self, idx, n, name="rng_index"):
         if idx is None:
             return None
         if (not isinstance(idx, torch.Tensor) or idx.device != self.device or idx.dtype != torch.int64 or idx.dim() != 1
-                or idx.shape[0] != n or not idx.is_contiguous()):
-            raise RuntimeError(f"rng_index must be a contiguous int64 tensor of shape [{n}] on {self.device}")
+                or (n is not None and idx.shape[0] != n) or not idx.is_contiguous()):
+            raise RuntimeError(f"{name} must be a contiguous int64 tensor" + (f" of shape [{n}]" if n is not None else "") +
+                               f" on {self.device}")
         return idx
 
-    def _plugin_sample_ex(self, wi, x0, T, variant, seed, offset, out, ctx, rng_index, ctx_read=False):
+    def _rows(self, row_index, m):
+        """Rows a call processes: all m of the arrays, or the rows a row_index names."""
+        self._chk_index(row_index, None, "row_index")
+        if row_index is not None and row_index.shape[0] > m:
+            raise RuntimeError(f"row_index names {row_index.shape[0]} rows, the arrays have {m}")
+        return m if row_index is None else row_index.shape[0]
+
+    def _plugin_sample_ex(self, wi, x0, T, variant, seed, offset, out, ctx, rng_index, ctx_read=False, row_index=None):
+        mk = torch.empty if row_index is None else torch.zeros   # (rows a row_index does not name stay untouched)
         if self._ops is not None:
             self._dev_chk(wi, "wi")
+            n = self._rows(row_index, wi.shape[0])
             if ctx is not None:
-                self._chk_ctx(ctx, wi.shape[0])
-            self._chk_index(rng_index, wi.shape[0])
+                self._chk_ctx(ctx, n)
+            self._chk_index(rng_index, n)
             if out is None:
-                out = (torch.empty((wi.shape[0], 3), dtype=torch.float32, device=self.device),
-                       torch.empty((wi.shape[0],), dtype=torch.float32, device=self.device))
+                out = (mk((wi.shape[0], 3), dtype=torch.float32, device=self.device),
+                       mk((wi.shape[0],), dtype=torch.float32, device=self.device))
             self._ops.plugin_sample_ex_out(self._hi, variant, wi, x0, _i64(seed), _i64(offset), T, out[0], out[1], ctx, rng_index,
-                                           ctx_read)
+                                           ctx_read, row_index)
             return out[0], out[1]
         wi = self._chk(wi, 3, "wi")
-        n = wi.shape[0]
-        x0 = self._chk(x0, 2, "x0", n)
+        m = wi.shape[0]
+        n = self._rows(row_index, m)
+        x0 = self._chk(x0, 2, "x0", m)
         if ctx is not None:
             self._chk_ctx(ctx, n)
         self._chk_index(rng_index, n)
         if out is None:
-            wo = torch.empty((n, 3), dtype=torch.float32, device=self.device)
-            pdf = torch.empty((n,), dtype=torch.float32, device=self.device)
+            wo = mk((m, 3), dtype=torch.float32, device=self.device)
+            pdf = mk((m,), dtype=torch.float32, device=self.device)
         else:
-            wo, pdf = self._chk(out[0], 3, "out wo", n), self._chk1(out[1], n, "out pdf")
-        o = _lib.opts(ctx_in=ctx, rng_index=rng_index) if ctx_read else _lib.opts(ctx_out=ctx, rng_index=rng_index)
+            wo, pdf = self._chk(out[0], 3, "out wo", m), self._chk1(out[1], m, "out pdf")
+        o = (_lib.opts(ctx_in=ctx, rng_index=rng_index, row_index=row_index) if ctx_read
+             else _lib.opts(ctx_out=ctx, rng_index=rng_index, row_index=row_index))
         with torch.cuda.device(self.device):
             _lib.check(self._L.bsdfd_plugin_sample_ex(self._h, variant, _ptr(wi), _ptr(x0), seed, offset, n, T,
                                                       _ptr(wo), _ptr(pdf), C.byref(o), self._stream()))
@@ -323,27 +345,33 @@ class FlowSampler:
 
     def plugin_pdf(self, wi, wo, T: int = 4, variant: int = _lib.PLUGIN_MEASURED,
                    out: Optional[torch.Tensor] = None, ctx_in: Optional[torch.Tensor] = None,
-                   ctx_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   ctx_out: Optional[torch.Tensor] = None, row_index: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``ctx_in``: the context an earlier ``plugin_sample`` / ``plugin_pdf`` call wrote (``ctx_out=``) for this very ``wi``
         array; ``ctx_out`` (``new_context(N)``): write it here (the call order of Mitsuba's path integrator: eval_pdf() for the
-        emitter sample first, sample() second — rendering/brdf_measured_disk.py:126,59).  At most one of the two."""
+        emitter sample first, sample() second — rendering/brdf_measured_disk.py:126,59).  At most one of the two.
+        ``row_index``: as in ``plugin_sample`` (row i reads wi / wo at row ``row_index[i]`` and writes pdf there)."""
         if ctx_out is not None and ctx_in is not None:
             raise RuntimeError("a call either writes a per-query context (ctx_out) or reads one (ctx_in), not both")
-        if ctx_in is not None or ctx_out is not None:
+        if ctx_in is not None or ctx_out is not None or row_index is not None:
             ctx, write = (ctx_in, False) if ctx_out is None else (ctx_out, True)
+            mk = torch.empty if row_index is None else torch.zeros
             if self._ops is not None:
                 self._dev_chk(wi, "wi")
-                self._chk_ctx(ctx, wi.shape[0])
+                n = self._rows(row_index, wi.shape[0])
+                if ctx is not None:
+                    self._chk_ctx(ctx, n)
                 if out is None:
-                    out = torch.empty((wi.shape[0],), dtype=torch.float32, device=self.device)
-                self._ops.plugin_pdf_ex_out(self._hi, variant, wi, wo, T, out, ctx, write)
+                    out = mk((wi.shape[0],), dtype=torch.float32, device=self.device)
+                self._ops.plugin_pdf_ex_out(self._hi, variant, wi, wo, T, out, ctx, write, row_index)
                 return out
             wi = self._chk(wi, 3, "wi")
-            n = wi.shape[0]
-            wo = self._chk(wo, 3, "wo", n)
-            self._chk_ctx(ctx, n)
-            pdf = torch.empty((n,), dtype=torch.float32, device=self.device) if out is None else self._chk1(out, n, "out pdf")
-            o = _lib.opts(ctx_out=ctx) if write else _lib.opts(ctx_in=ctx)
+            m = wi.shape[0]
+            n = self._rows(row_index, m)
+            wo = self._chk(wo, 3, "wo", m)
+            if ctx is not None:
+                self._chk_ctx(ctx, n)
+            pdf = mk((m,), dtype=torch.float32, device=self.device) if out is None else self._chk1(out, m, "out pdf")
+            o = _lib.opts(ctx_out=ctx, row_index=row_index) if write else _lib.opts(ctx_in=ctx, row_index=row_index)
             with torch.cuda.device(self.device):
                 _lib.check(self._L.bsdfd_plugin_pdf_ex(self._h, variant, _ptr(wi), _ptr(wo), n, T, _ptr(pdf),
                                                        C.byref(o), self._stream()))

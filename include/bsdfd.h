@@ -28,6 +28,14 @@
 extern "C" {
 #endif
 
+/* ABI version of this header: bumped whenever a struct grows or an entry point changes.  Structs (bsdfd_desc, bsdfd_opts,
+ * bsdfd_wf_scene) may grow AT THE END between versions and MUST be zero-initialised by the caller (memset / `= {0}`): a zero
+ * field always selects the behaviour of the version that did not have it.  A host checks bsdfd_abi_version() ==
+ * BSDFD_ABI_VERSION once after loading the library (the Python hosts do: _lib.lib()).
+ *   5: bsdfd_desc.reserved became bsdfd_desc.tile (values other than 0 / 16 / 32 are rejected, 0 = library default).
+ *   6: bsdfd_opts.row_index appended; bsdfd_abi_version() added. */
+#define BSDFD_ABI_VERSION 6
+
 #define BSDFD_OK 0
 #define BSDFD_EINVAL 1   /* bad argument / unsupported architecture */
 #define BSDFD_EHIP 2     /* a HIP runtime call failed */
@@ -36,16 +44,22 @@ extern "C" {
 #define BSDFD_DOMAIN_DISK 0       /* state = 2-D point on the unit disk          */
 #define BSDFD_DOMAIN_SPHERICAL 1  /* state = (theta, phi); net input [theta, sin phi, cos phi] */
 
-/* Arithmetic of the dense layer contractions (activations, Jacobian determinant,
- * base density and warps are always fp32 VALU). */
+/* Arithmetic of the dense layer contractions.  Activations, Jacobian determinant, base density and warps are fp32 VALU —
+ * with ONE exception: bsdfd_flow_samples_only in BSDFD_PREC_F16 (both tilings) evaluates the hidden layers' sigmoids in
+ * packed fp16 as well (see BSDFD_PREC_F16). */
 #define BSDFD_PREC_DEFAULT 0  /* = BSDFD_PREC_SPLIT3 */
 #define BSDFD_PREC_F32 1      /* v_mfma_f32_16x16x4_f32: exact fp32 FMA chains (validation mode) */
 #define BSDFD_PREC_SPLIT3 2   /* fp16 MFMA, operands split hi+lo, 3 products, fp32 accumulate (<=1e-4 parity).
                                * Range: hidden activations and tangents must stay below fp16's 65504 (they are
                                * O(1..100) for the reference's nets and inputs); beyond it the result is inf/NaN,
                                * never a silently wrong finite number. BSDFD_PREC_F32 has fp32 range. */
-#define BSDFD_PREC_F16 3      /* single fp16 MFMA pass (tcnn-class 1e-2 tolerance; reflow teacher sampling); the 32-query-tile
-                               * kernels of bsdfd_flow_samples_only also evaluate the hidden layers' sigmoids in fp16 */
+#define BSDFD_PREC_F16 3      /* single fp16 MFMA pass (tcnn-class 1e-2 tolerance; reflow teacher sampling).  The kernels of
+                               * bsdfd_flow_samples_only in this precision — 16- AND 32-query tiles — also evaluate the hidden
+                               * layers' sigmoids in packed fp16 (the 16-query kernels: every hidden layer; the 32-query
+                               * kernels keep the last hidden layer's in fp32): that call is its own fp16-class evaluation and
+                               * does NOT walk the trajectory of bsdfd_network_sampling(BSDFD_PREC_F16) bit for bit (agreement
+                               * ~2e-2, the class's tolerance).  Range: |pre-activation| must stay below ~4.5e4 (fp16's
+                               * largest finite value); beyond it sigma evaluates inf * 0 = NaN, never a wrong finite number. */
 
 /* Plugin post-processing variants (which MyBSDF the call mirrors). */
 #define BSDFD_PLUGIN_MEASURED 0    /* rendering/brdf_measured_{disk,spherical}.py */
@@ -71,11 +85,17 @@ typedef struct bsdfd_desc {
     int32_t base_hidden;    /* hidden width of the base-density net (16)                 */
     int32_t base_pe_bands;  /* positional-encoding bands of the base net (3)             */
     int32_t precision;      /* BSDFD_PREC_*                                              */
-    int32_t tile;           /* queries per wave64 tile of the Jacobian kernels: 0 = library default (overridable with
-                             * $BSDFD_TILE), 16 = the 16x16x32-MFMA kernels, 32 = the 32x32x16-MFMA kernels (the reference's two
-                             * plugin nets — disk 32x3, spherical 32x4 — in BSDFD_PREC_SPLIT3, and bsdfd_flow_samples_only of the
-                             * 64 x 6 spherical teacher in BSDFD_PREC_F16; silently 16 for anything else).
-                             * Both tilings implement the same operators to the same tolerance. */
+    int32_t tile;           /* queries per wave64 tile: 0 = library default (32 where such a kernel exists), 16 = the
+                             * 16x16x32-MFMA kernels (every net), 32 = the 32x32x16-MFMA kernels, which exist for
+                             *   (1) the reference's two plugin nets — disk 32x3, spherical 32x4 — in BSDFD_PREC_SPLIT3 (all calls),
+                             *   (2) bsdfd_flow_samples_only of the 64 x 6 spherical teacher in BSDFD_PREC_F16,
+                             *   (3) bsdfd_flow_samples_only of those two 32-wide nets in BSDFD_PREC_F16.
+                             * An explicit 32 for a (net, precision) with no such kernel at all is REJECTED by bsdfd_create
+                             * (BSDFD_EINVAL); where only some calls have one — (2), (3) — the others run 16-query tiles and
+                             * bsdfd_get_tile says which.  Product behaviour depends on this field alone: the library reads
+                             * no environment variable (the Python hosts map $BSDFD_TILE onto it for A/B runs).
+                             * Both tilings implement the same operators to the same tolerance.  Was `reserved` before ABI 5:
+                             * zero-initialise the struct. */
     const float* w_in;      /* [width, state_dim + 1 + 2 + 4*pe_bands], cols [state|alpha|PE(omega_i)] */
     const float* w_hidden;  /* [n_hidden-1, width, width]                                */
     const float* w_out;     /* [2, width]                                                */
@@ -167,6 +187,15 @@ typedef struct bsdfd_opts {
                                 * rng_index[i] instead of offset + i.  A wavefront that was bucketed by material
                                 * passes the rows' ORIGINAL lane indices here: the base draws then depend on neither
                                 * the bucketing nor the sharding / GPU count.                */
+    const int64_t* row_index;  /* sample / pdf / sample_pdf calls (ABI 6): device array [N]; row i of the call READS its
+                                * inputs (wi, x0, wo / wl) at row row_index[i] of the callers' arrays and WRITES its outputs
+                                * there.  A wavefront bucketed by material hands over the bucket permutation
+                                * (bsdfd_bucket_by_material's perm) with the callers' lane-ordered arrays: no gathered copy of
+                                * the inputs, no scatter of the results (the dispatch it replaces: one plugin instance per
+                                * material called on its lanes, rendering/matpreview/disney_bsdf_array0_envmap.xml +
+                                * rendering/brdf_measured_disk.py:140).  seg_end, the per-query context and rng_index stay
+                                * indexed by i; without rng_index the Philox counter of row i is offset + row_index[i].
+                                * Rows not named by row_index are not touched.  Entries must be distinct.               */
 } bsdfd_opts;
 int bsdfd_plugin_sample_ex(bsdfd_handle h, int32_t variant, const float* wi, const float* x0, uint64_t seed,
                            uint64_t offset, int64_t N, int32_t T, float* wo, float* pdf_sa, const bsdfd_opts* opts,
@@ -336,6 +365,8 @@ int bsdfd_wf_shade(const bsdfd_wf_scene* scene, const float* env, int32_t row_be
 
 const char* bsdfd_last_error(void);
 const char* bsdfd_version(void);
+/* BSDFD_ABI_VERSION the library was compiled with (see the top of this header). */
+int32_t bsdfd_abi_version(void);
 
 #ifdef __cplusplus
 }

@@ -201,19 +201,21 @@ class Oracle:
         return loggau + logvon
 
     # ---- the four operators (rendering/utils/mlp_brdf_sampling.py) -------
-    def network_sampling(self, omega_i, x0, T):
+    def network_sampling(self, omega_i, x0, T, return_acc=False):
         """``network_sampling_disk`` :17-51 (T=4) / ``network_sampling_spherical``
         :106-140 (T=8) with the base draw ``x0`` supplied by the caller (the
         reference's torch RNG stream is not reproducible elsewhere).
-        Returns (x_T [N,2], pdf [N])."""
+        Returns (x_T [N,2], pdf [N]); ``return_acc``: also prod 1/det J (the row
+        filter of the error metric)."""
         p0 = np.exp(self.base_log_prob(x0, omega_i))
         x, acc = self.flow(x0, omega_i, T, reverse=False)
-        return x, p0 * acc
+        return (x, p0 * acc, acc) if return_acc else (x, p0 * acc)
 
-    def network_pdf(self, omega_o, omega_i, T):
+    def network_pdf(self, omega_o, omega_i, T, return_acc=False):
         """``network_pdf_disk`` :69-103 / ``network_pdf_spherical`` :144-181."""
         x, acc = self.flow(omega_o, omega_i, T, reverse=True)
-        return np.exp(self.base_log_prob(x, omega_i)) * acc
+        pdf = np.exp(self.base_log_prob(x, omega_i)) * acc
+        return (pdf, acc) if return_acc else pdf
 
 
 # ---------------------------------------------------------------------------
@@ -227,30 +229,31 @@ def cart_to_spher(v):
     return np.stack([theta, phi], 1)
 
 
-def plugin_sample_disk(orc, wi3, x0, T=4):
+def plugin_sample_disk(orc, wi3, x0, T=4, return_acc=False):
     """rendering/brdf_measured_disk.py:59-82 (everything before ``measured.eval``):
     omega_i = wi[:, :2]; flow; r^2 >= 0.995 -> wo=(0,0), pdf=0;
     z = sqrt(relu(1-r^2)) (rendering/utils/mitsuba_brdf_draw.py:40-43);
     pdf_sa = pdf * cos(theta_o).  The cos(theta_i) > 0 lane mask is applied by
     the caller to the *weight*, not to wo/pdf (:64,101), so it is not applied here."""
     wi3 = np.asarray(wi3, dtype=orc.dtype)
-    wo2, pdf = orc.network_sampling(wi3[:, :2], x0, T)
+    wo2, pdf, acc = orc.network_sampling(wi3[:, :2], x0, T, return_acc=True)
     r2 = wo2[:, 0] ** 2 + wo2[:, 1] ** 2
     valid = r2 < 0.995
     wo2 = np.where(valid[:, None], wo2, 0.0)
     pdf = np.where(valid, pdf, 0.0)
     z = np.sqrt(np.maximum(1.0 - (wo2 ** 2).sum(1), 0.0))
     wo3 = np.concatenate([wo2, z[:, None]], 1)
-    return wo3, pdf * z
+    return (wo3, pdf * z, acc) if return_acc else (wo3, pdf * z)
 
 
-def plugin_pdf_disk(orc, wi3, wo3, T=4):
+def plugin_pdf_disk(orc, wi3, wo3, T=4, return_acc=False):
     """rendering/brdf_measured_disk.py:112-124."""
     wi3 = np.asarray(wi3, dtype=orc.dtype)
     wo3 = np.asarray(wo3, dtype=orc.dtype)
-    pdf = orc.network_pdf(wo3[:, :2], wi3[:, :2], T)
+    pdf, acc = orc.network_pdf(wo3[:, :2], wi3[:, :2], T, return_acc=True)
     ok = (wi3[:, 2] > 0) & (wo3[:, 2] > 0)
-    return np.where(ok, pdf * wo3[:, 2], 0.0)
+    out = np.where(ok, pdf * wo3[:, 2], 0.0)
+    return (out, acc) if return_acc else out
 
 
 def frame_sin_theta(v):
@@ -265,34 +268,37 @@ def _inv_sin_clamped(sin_t, dtype):
         return np.clip(1.0 / sin_t, 1.0, dtype.type(fmax))
 
 
-def plugin_sample_spherical(orc, wi3, x0, T=8, full_sphere=False):
+def plugin_sample_spherical(orc, wi3, x0, T=8, full_sphere=False, return_acc=False):
     """rendering/brdf_measured_spherical.py:69-91 (``full_sphere=False``) and
     rendering/bsdf_myresult.py:59-84 (``full_sphere=True``: no cos(theta_o) guard,
     |sin theta_o| in the Jacobian)."""
     wi3 = np.asarray(wi3, dtype=orc.dtype)
-    wo2, pdf = orc.network_sampling(cart_to_spher(wi3), x0, T)
+    wo2, pdf, acc = orc.network_sampling(cart_to_spher(wi3), x0, T, return_acc=True)
     st, ct = np.sin(wo2[:, 0]), np.cos(wo2[:, 0])
     pdf = np.where(st > 0.00005, pdf, 0.0)
     if not full_sphere:
         pdf = np.where(ct > 0, pdf, 0.0)
     sp, cp = np.sin(wo2[:, 1]), np.cos(wo2[:, 1])
     wo3 = np.stack([cp * st, sp * st, ct], 1)  # sph_to_dir :31-34
-    return wo3, pdf * _inv_sin_clamped(frame_sin_theta(wo3), orc.dtype)
+    out = pdf * _inv_sin_clamped(frame_sin_theta(wo3), orc.dtype)
+    return (wo3, out, acc) if return_acc else (wo3, out)
 
 
-def plugin_pdf_spherical(orc, wi3, wo3, T=8, full_sphere=False):
+def plugin_pdf_spherical(orc, wi3, wo3, T=8, full_sphere=False, return_acc=False):
     """rendering/brdf_measured_spherical.py:122-137 / rendering/bsdf_myresult.py:115-133
     (the latter has neither the sin-theta guard nor the cos masks)."""
     wi3 = np.asarray(wi3, dtype=orc.dtype)
     wo3 = np.asarray(wo3, dtype=orc.dtype)
     wo2 = cart_to_spher(wo3)
-    pdf = orc.network_pdf(wo2, cart_to_spher(wi3), T)
+    pdf, acc = orc.network_pdf(wo2, cart_to_spher(wi3), T, return_acc=True)
     inv = _inv_sin_clamped(frame_sin_theta(wo3), orc.dtype)
     if full_sphere:
-        return pdf * inv
-    pdf = np.where(np.sin(wo2[:, 0]) > 0.00005, pdf, 0.0)
-    ok = (wi3[:, 2] > 0) & (wo3[:, 2] > 0)
-    return np.where(ok, pdf * inv, 0.0)
+        out = pdf * inv
+    else:
+        pdf = np.where(np.sin(wo2[:, 0]) > 0.00005, pdf, 0.0)
+        ok = (wi3[:, 2] > 0) & (wo3[:, 2] > 0)
+        out = np.where(ok, pdf * inv, 0.0)
+    return (out, acc) if return_acc else out
 
 
 # ---------------------------------------------------------------------------

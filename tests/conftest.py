@@ -19,6 +19,10 @@ GOLDEN_CASES = [
 ]
 
 
+# the two HARD cases again at 16 384 rows (tests/golden/make_golden.py --large): a p99 there is the 164th-largest row, not the 20th
+LARGE_CASES = ["chm_orange_rgb_spherical_n16k", "aniso_miro_7_rgb_spherical_complex_n16k"]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
@@ -28,7 +32,8 @@ def load_case(stem):
     from bsdf_diffusion_sampling_amd import weights as W
 
     g = np.load(os.path.join(GOLDEN, stem + ".npz"))
-    fw = W.load(os.path.join(W.DATA_DIR, stem + ".bsdfw"))
+    wstem = stem[: -len("_n16k")] if stem.endswith("_n16k") else stem
+    fw = W.load(os.path.join(W.DATA_DIR, wstem + ".bsdfw"))
     return g, fw
 
 

@@ -15,7 +15,9 @@ SURVEY.md §8(c):
   * ``D_base.sample`` monkey-patched to return a stored x0, so the deterministic
     part x0 -> (x_T, pdf) is bit-reproducible (the torch RNG stream is not).
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py            # the 2 048-row fixtures <stem>.npz (+ kappa sweep, toy)
+        python tests/golden/make_golden.py --large    # 16 384-row fixtures <stem>_n16k.npz of the two HARD cases (LARGE_CASES):
+                                                      # the per-row arrays of the operators only, so that a p99 has 160 rows
 """
 import os
 import sys
@@ -205,7 +207,30 @@ CASES = [
     ("aniso_miro_7_rgb", "spherical", "complex", 31),
 ]
 
+LARGE_N = 16384
+LARGE_CASES = [c for c in CASES if (c[0], c[1], c[2]) in (("chm_orange_rgb", "spherical", None), ("aniso_miro_7_rgb", "spherical", "complex"))]
+LARGE_KEYS = ("wi", "x0", "pdf_wo_a", "pdf_wo_b", "sample_x_f64", "sample_pdf_f64")
+
+
+def run_large():
+    """The hard cases again at LARGE_N rows (same seeds, same code path: only N differs)."""
+    global N
+    N = LARGE_N
+    for mat, dom, var, seed in LARGE_CASES:
+        res = run_case(mat, dom, var, seed)
+        T = res["meta_T"]
+        keep = {k: v for k, v in res.items() if k.startswith("meta_") or k in LARGE_KEYS or
+                k in (f"sample_x_T{T}", f"sample_pdf_T{T}", f"pdf_a_T{T}", f"pdf_b_T{T}")}
+        stem = f"{mat}_{dom}" + (f"_{var}" if var else "") + "_n16k"
+        np.savez_compressed(os.path.join(HERE, stem + ".npz"), **keep)
+        print("wrote", stem, {k: v.shape for k, v in keep.items() if hasattr(v, "shape") and v.ndim}, flush=True)
+    assert not os.path.exists(os.path.join(REF, "utils", "__pycache__")), "wrote into the reference tree"
+
+
 if __name__ == "__main__":
+    if "--large" in sys.argv[1:]:
+        run_large()
+        sys.exit(0)
     for mat, dom, var, seed in CASES:
         res = run_case(mat, dom, var, seed)
         stem = f"{mat}_{dom}" + (f"_{var}" if var else "")

@@ -94,9 +94,10 @@ def spherical_pdf(db, ds, wi3, wo3, T, full):
     return torch.where(ok, pdf * inv, torch.zeros_like(pdf))
 
 
-def run_case(material, domain, variant, seed):
-    stem = f"{material}_{domain}" + (f"_{variant}" if variant else "")
+def run_case(material, domain, variant, seed, suffix=""):
+    stem = f"{material}_{domain}" + (f"_{variant}" if variant else "") + suffix
     g = np.load(os.path.join(HERE, stem + ".npz"))
+    G.N = g["wi"].shape[0]
     T = int(g["meta_T"])
     full = material.startswith("bsdf_")
     wi = torch.from_numpy(g["wi"])
@@ -149,6 +150,16 @@ def run_case(material, domain, variant, seed):
 
 
 if __name__ == "__main__":
+    if "--large" in sys.argv[1:]:   # the hard case at 16 384 rows (tests/golden/make_golden.py --large first)
+        for mat, dom, var, seed in G.LARGE_CASES:
+            if var:
+                continue
+            stem, res = run_case(mat, dom, var, seed, suffix="_n16k")
+            res = {k: v for k, v in res.items() if k not in ("sample_theta_phi", "wi_theta_phi")}
+            np.savez_compressed(os.path.join(HERE, stem + "_plugin.npz"), **res)
+            print("wrote", stem + "_plugin", {k: v.shape for k, v in res.items() if hasattr(v, "shape") and v.ndim}, flush=True)
+        assert not os.path.exists(os.path.join(G.REF, "utils", "__pycache__")), "wrote into the reference tree"
+        sys.exit(0)
     for mat, dom, var, seed in G.CASES:
         if var:  # the 64-wide teacher is not loaded by any plugin
             continue

@@ -66,12 +66,21 @@ def test_bench_line_single_gpu_with_secondary_and_cpu_baseline():
     assert ac["value"] is not None and ac["value"] > 0, ac
     assert d["roofline"]["traffic_source"]["measured_in_this_run"] is False and "@" in d["roofline"]["traffic_source"]["ref"]
     assert ib["tile_queries"] == d["config"]["tile_queries"] == 32     # the judged kernel: csrc/flow32.hip
-    board = d["roofline"]["board"]   # rocm-smi while the judged kernel runs back to back: null values where the tool is absent
-    assert "error" not in board and (board["socket_power_w"] is None or 200 < board["socket_power_w"] < 1600), board
+    # energy is a first-class figure (the kernels are power-limited): socket power polled while the workload's own
+    # passes run back to back, joules per million sample()+pdf() queries — for the judged workload and every secondary one
+    board = d["roofline"]["board"]
+    assert "error" not in board and board["source"] is not None and board["samples"] >= 2, board
+    assert 200 < board["socket_power_w"] < 1600 and 200 < d["roofline"]["socket_power_w"] < 1600, board
+    assert d["roofline"]["joule_per_Mquery"] == board["joule_per_Mquery"]
+    # consistency: J/Mquery x Mquery/s = W
+    assert abs(board["joule_per_Mquery"] * board["Mqueries_per_s"] - board["socket_power_w"]) < 1e-6 * board["socket_power_w"]
+    assert 0.2 < board["joule_per_Mquery"] < 5.0, board                 # ~1.1 J per Mquery at 1.2 Gsamples/s and 1.35 kW
     for name in ("disk_1Mi_T4", "spherical_16Mi_T8", "mixed_16Mi", "teacher_64x6_4Mi_T128", "complex64_1Mi_T8"):
         s = d["secondary"][name]
         assert "error" not in s, s
         assert s["value"] > 0 and 0 < s["frac"] < 1
+        assert "error" not in s["board"] and 200 < s["socket_power_w"] < 1600 and s["joule_per_Mquery"] > 0, s["board"]
+    assert d["secondary"]["mixed_16Mi"]["config"]["row_index"] is True
     assert d["encoding_pass"]["bound"] == "hbm" and d["encoding_pass"]["frac"] > 0.3
 
 

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
-from conftest import GOLDEN_CASES, load_case, same_density  # noqa: E402
+from conftest import GOLDEN_CASES, LARGE_CASES, load_case, same_density  # noqa: E402
 from oracle import bsdf_oracle as O  # noqa: E402
 
 
@@ -91,7 +91,7 @@ def _tail_bound(name, r, r32):
 
 
 @pytest.mark.parametrize("precision", ["f32", "split3"])
-@pytest.mark.parametrize("stem", GOLDEN_CASES)
+@pytest.mark.parametrize("stem", GOLDEN_CASES + LARGE_CASES)
 def test_network_sampling_vs_oracle_and_golden(stem, precision):
     g, fw = load_case(stem)
     T = int(g["meta_T"])
@@ -115,7 +115,7 @@ def test_network_sampling_vs_oracle_and_golden(stem, precision):
 
 
 @pytest.mark.parametrize("precision", ["f32", "split3"])
-@pytest.mark.parametrize("stem", GOLDEN_CASES)
+@pytest.mark.parametrize("stem", GOLDEN_CASES + LARGE_CASES)
 def test_network_pdf_vs_oracle_and_golden(stem, precision):
     g, fw = load_case(stem)
     s = _sampler(fw, precision)
@@ -794,7 +794,7 @@ PLUGIN_CASES = ["aniso_miro_7_rgb_disk", "chm_orange_rgb_disk", "vch_silk_blue_r
                 "chm_orange_rgb_spherical", "bsdf_3_spherical"]
 
 
-@pytest.mark.parametrize("stem", PLUGIN_CASES)
+@pytest.mark.parametrize("stem", PLUGIN_CASES + ["chm_orange_rgb_spherical_n16k"])
 def test_plugin_level_vs_reference_plugin_goldens(stem):
     """Plugin-level parity against tests/golden/<stem>_plugin.npz: the reference's own operators followed by the plugins'
     tensor ops (rendering/brdf_measured_disk.py:59-82,112-124, brdf_measured_spherical.py:35-39,69-91,122-137,

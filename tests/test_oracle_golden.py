@@ -34,6 +34,30 @@ def test_sampling_matches_reference_fp64(golden_case):
     assert np.array_equal(np.sign(p), np.sign(g["sample_pdf_f64"]))
 
 
+@pytest.mark.parametrize("stem", ["chm_orange_rgb_spherical_n16k", "aniso_miro_7_rgb_spherical_complex_n16k"])
+def test_large_fixtures_pin_the_oracle_too(stem):
+    """The 16 384-row fixtures of the two hard cases (make_golden.py --large): the oracle reproduces the reference's fp64 run
+    to round-off and its fp32 runs (sample, pdf at produced and at fresh points) to fp32 noise — same bounds as the small ones."""
+    from conftest import load_case
+    g, fw = load_case(stem)
+    assert g["wi"].shape[0] == 16384
+    orc = O.Oracle(fw)
+    T = int(g["meta_T"])
+    x, p, acc = orc.network_sampling(g["wi"], g["x0"], T, return_acc=True)
+    assert np.abs(x - g["sample_x_f64"]).max() < 1e-10
+    assert rel(p, g["sample_pdf_f64"]).max() < 1e-9
+    assert np.abs(x - g[f"sample_x_T{T}"]).max() < 1e-4
+    r = rel(p, g[f"sample_pdf_T{T}"])[np.abs(1.0 / acc) > 1e-3]
+    assert np.median(r) < 1e-5 and np.percentile(r, 99) < 2e-4
+    for which in "ab":
+        pp = orc.network_pdf(g[f"pdf_wo_{which}"], g["wi"], T)
+        ref = g[f"pdf_{which}_T{T}"]
+        big = np.abs(ref) > 1e-6 * np.abs(ref).max()
+        r = rel(pp, ref)[big]
+        assert np.median(r) < 1e-5 and np.percentile(r, 99) < 1e-3
+        assert np.mean(np.sign(pp[big]) == np.sign(ref[big])) > 0.999
+
+
 @pytest.mark.parametrize("T", [1, 4, 8])
 def test_sampling_matches_reference_fp32(golden_case, T):
     _, g, fw = golden_case
@@ -163,7 +187,7 @@ PLUGIN_CASES = ["aniso_miro_7_rgb_disk", "chm_orange_rgb_disk", "vch_silk_blue_r
                 "chm_orange_rgb_spherical", "bsdf_3_spherical"]
 
 
-@pytest.mark.parametrize("stem", PLUGIN_CASES)
+@pytest.mark.parametrize("stem", PLUGIN_CASES + ["chm_orange_rgb_spherical_n16k"])
 def test_plugin_level_oracle_vs_reference_plugin_goldens(stem):
     """SURVEY.md §8(c) last row: plugin-level (wo3, pdf_sa) after guards.  tests/golden/<stem>_plugin.npz holds the
     reference's own operators followed by the plugins' tensor ops (make_plugin_golden.py names the lines); the oracle's

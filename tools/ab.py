@@ -24,18 +24,33 @@ from bsdf_diffusion_sampling_amd import weights as W  # noqa: E402
 from bsdf_diffusion_sampling_amd.sampler import FlowSampler  # noqa: E402
 
 
+LAST_MHZ = [None]   # in-kernel shader clock of the launches kernel_ms() timed last (bsdfd_profile_clock_mhz)
+
+
 def kernel_ms(smp, fn, reps, warm=3):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    out = []
+    out, mhz = [], []
     for _ in range(reps):
         smp.set_profiling(True)
         fn()
         n, ms = smp.profile_read()
         out.append(ms / max(n, 1))
+        mhz.append(smp.profile_clock_mhz())
     smp.set_profiling(False)
+    LAST_MHZ[0] = float(np.median(mhz)) if mhz else None
     return float(np.median(out)), float(np.min(out))
+
+
+def energy(run, n, seconds):
+    """J per million queries + socket watts of `run` back to back (bsdf_diffusion_sampling_amd/power.py): the flow kernels are
+    power-limited, so an A/B is decided by joules per query — time follows."""
+    if seconds <= 0:
+        return {}
+    from bsdf_diffusion_sampling_amd.power import energy_probe
+    e = energy_probe(lambda k: run(), n, seconds=seconds, sync=torch.cuda.synchronize)
+    return {"joule_per_Mquery": e["joule_per_Mquery"], "watts": e["socket_power_w"], "sclk_mhz": e["sclk_mhz"], "power_samples": e["samples"]}
 
 
 def settle(smp, wi, T, ms=150.0):
@@ -79,6 +94,7 @@ def main():
     ap.add_argument("--only", default="disk8,disk4,sph8,cplx8,teacher")
     ap.add_argument("--acc", action="store_true")
     ap.add_argument("--reps", type=int, default=15)
+    ap.add_argument("--energy-s", type=float, default=0.8, help="seconds of back-to-back sample()+pdf() pairs per workload for J/query (0: skip)")
     a = ap.parse_args()
     only = set(a.only.split(","))
     dev = torch.device("cuda", 0)
@@ -95,10 +111,15 @@ def main():
         pp = torch.empty((n,), device=dev)
         settle(smp, wi, T)
         ms_s, mn_s = kernel_ms(smp, lambda: smp.plugin_sample(wi, None, T=T, seed=3, out=(wo, ps)), a.reps)
+        mhz_s = LAST_MHZ[0]
         ms_p, mn_p = kernel_ms(smp, lambda: smp.plugin_pdf(wi, wo, T=T, out=pp), a.reps)
+        mhz_p = LAST_MHZ[0]
         fl = smp.flops_per_query(T) * n
         out[name] = {"sample_ms": ms_s, "pdf_ms": ms_p, "sample_min": mn_s, "pdf_min": mn_p,
-                     "frac": fl / (0.5 * (ms_s + ms_p) * 1e-3) / 2.5e15}
+                     "frac": fl / (0.5 * (ms_s + ms_p) * 1e-3) / 2.5e15, "sample_mhz": mhz_s, "pdf_mhz": mhz_p,
+                     "sample_Mcycles": ms_s * (mhz_s or 0) * 1e-3, "pdf_Mcycles": ms_p * (mhz_p or 0) * 1e-3}
+        out[name].update(energy(lambda: (smp.plugin_sample(wi, None, T=T, seed=3, out=(wo, ps)), smp.plugin_pdf(wi, wo, T=T, out=pp)),
+                                n, a.energy_s))
         smp.close()
 
     if "disk8" in only:
@@ -146,7 +167,8 @@ def main():
         ms, mn = kernel_ms(s, lambda: s.flow_samples_only(cond, x0, T=T), max(a.reps // 3, 3), warm=1)
         w = fw.width
         fwd = 2 * (fw.in_dim * w + (fw.n_hidden - 1) * w * w + 2 * w) * T
-        out["teacher"] = {"ms": ms, "min": mn, "frac": n * fwd / (ms * 1e-3) / 2.5e15}
+        out["teacher"] = {"ms": ms, "min": mn, "frac": n * fwd / (ms * 1e-3) / 2.5e15, "mhz": LAST_MHZ[0]}
+        out["teacher"].update(energy(lambda: s.flow_samples_only(cond, x0, T=T), n, a.energy_s))
         s.close()
     print(json.dumps(out), flush=True)
 

@@ -30,3 +30,20 @@ for t in tags:
     fz = [r["fusedsph8"]["vs_two_calls_p999"] for r in rows if r["tag"] == t and "fusedsph8" in r and "vs_two_calls_p999" in r["fusedsph8"]]
     if fz:
         print(t, "fused spherical vs two launches (max |dwo|, p99.9 rel pdf_wo, p99.9 rel pdf_wl):", " ".join("%.1e" % x for x in fz[0]))
+# energy next to time (the kernels are power-limited: what an optimisation buys is what it saves in joules per query)
+ew = [w for w in dict.fromkeys(w for w, _ in keys) if any(w in r and "joule_per_Mquery" in r[w] for r in rows)]
+if ew:
+    print("%-14s" % "J/Mquery | W | in-kernel MHz" + "".join("%26s" % w for w in ew))
+    for t in tags:
+        line = "%-14s" % t
+        for w in ew:
+            rr = [r[w] for r in rows if r["tag"] == t and w in r and r[w].get("joule_per_Mquery")]
+            if rr:
+                j = float(np.median([x["joule_per_Mquery"] for x in rr]))
+                j0 = [x[w]["joule_per_Mquery"] for x in rows if x["tag"] == tags[0] and w in x and x[w].get("joule_per_Mquery")]
+                watts = float(np.median([x["watts"] for x in rr]))
+                mhz = [x.get("sample_mhz") or x.get("mhz") for x in rr if (x.get("sample_mhz") or x.get("mhz"))]
+                line += "%9.4f(%5.3f)%5.0fW%5.0f" % (j, j / float(np.median(j0)) if j0 else float("nan"), watts, float(np.median(mhz)) if mhz else 0)
+            else:
+                line += "%26s" % "-"
+        print(line)
