@@ -356,8 +356,11 @@ class MixedMaterials:
         from bsdf_diffusion_sampling_amd.materials import WavefrontPipeline
         # $BSDFD_BENCH_MIXED_GATHER=1: round 4/5's form — gather of wi and scatter of the results as kernels of their own on side
         # streams; default (round 6): the flow kernels read and write lane order through the bucket permutation (bsdfd_opts.row_index)
-        self.direct = not os.environ.get("BSDFD_BENCH_MIXED_GATHER")
-        self.pipe = None if os.environ.get("BSDFD_BENCH_MIXED_SERIAL") else WavefrontPipeline(self.tab, direct=self.direct)
+        #   (what the pipeline itself picks up to WavefrontPipeline.DIRECT_MAX_LANES = 8 Mi lanes; at this workload's 16 Mi the
+        #    gather form is 5 % faster and moves 0.7x the HBM-side bytes: profiles/r06_ab/mixed_*); $BSDFD_BENCH_MIXED_DIRECT=1 forces it
+        force = True if os.environ.get("BSDFD_BENCH_MIXED_DIRECT") else (False if os.environ.get("BSDFD_BENCH_MIXED_GATHER") else None)
+        self.direct = force if force is not None else self.n_local <= WavefrontPipeline.DIRECT_MAX_LANES
+        self.pipe = None if os.environ.get("BSDFD_BENCH_MIXED_SERIAL") else WavefrontPipeline(self.tab, direct=force)
         self.wave = None
         self._out = None
 

@@ -285,6 +285,7 @@ def expected_flow_kernels(variant: str = "async") -> Dict[str, Dict[str, int]]:
             # fragment per 8 units) the forwarding-hazard check must see: 2 (3) hidden layers in front of the last one x 2 fragments
             out[f"flow_kernel32ILi{dom}ELb{jac}ELb{fused}ELb{split}EE"] = {"async": 0, "waits": 0, "sel": 0 if split else (32, 48)[dom]}
     out["flow_kernel32wE"] = {"async": 0, "waits": 0, "sel": 160}   # the 64 x 6 fp16 teacher on 32-query tiles: 5 layers x 4 fragments
+    out["flow_kernel32cE"] = {"async": 0, "waits": 0}               # the 64 x 6 split3 net with the Jacobian on 32-query tiles (round 6)
     return out
 
 

@@ -1199,6 +1199,7 @@ struct bsdfd_ctx {
     // 32-query-tile kernels (flow32.hip): which modes run them, and their weight image.  tile[m] = queries per wave tile of
     // mode m's kernel (16 | 32), img_of[m] / img_bytes[m] = the image that kernel reads (= its dynamic LDS)
     char* d_img32;
+    int ctx_v4_32;   // f32x4 records per 32-query tile of the per-query context (bsdfd_tile32_context_v4)
     int tile[3];
     const char* img_of[3];
     int img_bytes[3];
@@ -1726,6 +1727,7 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
     // 16-query tiles — silently under the default, with an error when 32 was asked for explicitly and cannot be honoured at all.
     const int want_tile = d->tile == 0 ? kDefaultTile : d->tile;
     const bool t32 = want_tile == 32 && bsdfd_tile32_supported(*d, prec);
+    h->ctx_v4_32 = bsdfd_tile32_context_v4(*d, prec);
     for (int m = 0; m < 3; ++m) {
         h->tile[m] = 16; h->img_of[m] = h->d_img; h->img_bytes[m] = h->lds_bytes[m] = h->L.total;
         h->threads[m] = threads_for(h->width / 16);
@@ -1735,7 +1737,7 @@ int bsdfd_create(const bsdfd_desc* d, bsdfd_handle* out) {
         e = hipMalloc(reinterpret_cast<void**>(&h->d_img32), img32.size());
         if (e == hipSuccess) e = hipMemcpy(h->d_img32, img32.data(), img32.size(), hipMemcpyHostToDevice);
         for (int m = 0; m < 3; ++m)
-            if (bsdfd_kernel32(*d, prec, m)) {
+            if (bsdfd_kernel32(*d, prec, m) && (d->tile == 32 || !bsdfd_kernel32_opt_in(*d, prec, m))) {
                 h->tile[m] = 32; h->img_of[m] = h->d_img32; h->img_bytes[m] = (int)img32.size();
                 h->lds_bytes[m] = bsdfd_kernel32_lds_bytes(*d, prec, m);
                 h->threads[m] = bsdfd_kernel32_threads(*d, prec, m);
@@ -1878,7 +1880,7 @@ int bsdfd_plugin_pdf(bsdfd_handle h, int32_t variant, const float* wi, const flo
 int64_t bsdfd_context_bytes(bsdfd_handle h, int64_t N, int32_t n_segments) {
     if (!h || N < 0 || n_segments < 1) return -1;
     // per 16-query tile: cacc[NM] per lane + bo per query, 16 B each; the 32-query-tile kernels store (4 x 64 + 32) x 16 B per tile
-    if (h->tile[1] == 32) return ((N + 31) / 32 + n_segments) * (int64_t)((4 * 64 + 32) * 16);
+    if (h->tile[1] == 32) return ((N + 31) / 32 + n_segments) * (int64_t)(h->ctx_v4_32 * 16);
     const int64_t per_tile = ((int64_t)(h->width / 16) * 64 + 16) * 16;
     return ((N + 15) / 16 + n_segments) * per_tile;
 }

@@ -61,6 +61,16 @@ constexpr int FR32 = 64 * 16;  // bytes of one A fragment (32 rows x 16 K-values
 #ifndef BSDFD_T32_FUSED_SPH_WAVES
 #define BSDFD_T32_FUSED_SPH_WAVES 2   // the fused spherical sample+pdf kernel keeps more state across its two Euler loops
 #endif
+#ifndef BSDFD_T32_SPH_COND_SPLIT
+#define BSDFD_T32_SPH_COND_SPLIT 0   // the SPHERICAL conditioning term as split-fp16 MFMAs with all FOUR products of the two-way splits (8 MFMAs)
+#endif                               // instead of 11 exact-fp32 v_mfma_f32_32x32x2_f32.  Round 6, NEGATIVE: -0.5 % kernel time (T = 8) for 6-10 % of
+                                     // the accuracy margin (worst of the 50 spherical-domain sets at 65 536 queries: sample 5.9e-5 -> 6.5e-5, pdf at
+                                     // produced directions 6.7e-5 -> 7.2e-5, at fresh ones 8.6e-5 -> 9.1e-5 [9.8e-5]; profiles/r06_ab/ab32_spherical_*)
+#ifndef BSDFD_T32_SPH_FOLD_T0
+#define BSDFD_T32_SPH_FOLD_T0 1      // spherical d/dtheta tangent through a folded matrix: the layer-1 tangent is g1 . W1[:, theta] with a CONSTANT
+#endif                               // column, so W2 (g1 . W1[:, theta]) = F_theta g1, F_theta = W2 diag(W1[:, theta]) packed by the host (the disk
+                                     // kernel's F_i).  Per step 16 multiplies and the read of W1[:, theta] less, the same MFMAs and splits.
+                                     // Round 6: -1.1 % kernel time, -1.6 % J/query (T = 8), accuracy unchanged on all 50 sets (same file)
 #ifndef BSDFD_T32_JAC2
 #define BSDFD_T32_JAC2 0         // A/B knob (round 6; negative, profiles/r06_ab/): the Jacobian-ONLY contractions (folded matrices, spherical
 #endif                           // tangent layers) in TWO products — 1: x rounded to fp16, no x_lo terms (and no hi/lo split of those vectors);
@@ -77,11 +87,11 @@ struct L32 {
     static constexpr bool SPH = DOMAIN == BSDFD_DOMAIN_SPHERICAL;
     static constexpr int NH = SPH ? 4 : 3;
     static constexpr int A1 = 0;                                   // layer-1 state fragment
-    static constexpr int WT0 = A1 + FR32;                          // spherical: W1[:, theta] in accumulator layout, 64 lanes x 16 floats
-    static constexpr int WC = WT0 + (SPH ? 64 * 64 : 0);           // conditioning: disk 4 fragments (hi c0, hi c1, lo c0, lo c1); spherical 11 x 64 floats
-    static constexpr int WH = WC + (SPH ? 11 * 256 : 4 * FR32);    // hidden matrices W2 .. W_NH: 4 fragments each
-    static constexpr int WF = WH + (NH - 1) * 4 * FR32;            // disk: F0, F1 = W2 diag(W1[:, i])
-    static constexpr int WG = WF + (SPH ? 0 : 8 * FR32);           // G0, G1 = W_NH^T diag(Wout[j, :])
+    static constexpr int WT0 = A1 + FR32;                          // spherical without BSDFD_T32_SPH_FOLD_T0: W1[:, theta] in accumulator layout, 64 lanes x 16 floats
+    static constexpr int WC = WT0 + ((SPH && !BSDFD_T32_SPH_FOLD_T0) ? 64 * 64 : 0);   // conditioning: disk 4 fragments (hi c0, hi c1, lo c0, lo c1); spherical 11 x 64 floats
+    static constexpr int WH = WC + ((SPH && !BSDFD_T32_SPH_COND_SPLIT) ? 11 * 256 : 4 * FR32);    // hidden matrices W2 .. W_NH: 4 fragments each
+    static constexpr int WF = WH + (NH - 1) * 4 * FR32;            // disk: F0, F1 = W2 diag(W1[:, i]); spherical (BSDFD_T32_SPH_FOLD_T0): F_theta
+    static constexpr int WG = WF + (SPH ? (BSDFD_T32_SPH_FOLD_T0 ? 4 * FR32 : 0) : 8 * FR32);   // G0, G1 = W_NH^T diag(Wout[j, :])
     static constexpr int WOUT = WG + 8 * FR32;                     // 2 halves x 16 x (Wout[0][u], Wout[1][u]) floats
     static constexpr int BW1 = WOUT + 256;                         // base net layer 1: 7 x 64 floats (A operands of the 32x32x2 MFMA)
     static constexpr int BB1 = BW1 + 7 * 256;                      // 2 halves x 8 floats
@@ -399,7 +409,7 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
             }
             e[10] = yh;
             // ---------------- conditioning term c = W1[:, PE] PE(omega_i) -----------------------------
-            if (!SPH) {   // split-fp16: the lane's 11 values are K slots of two K = 16 chunks (the 16-query kernels' SPLIT_PRO)
+            if (!SPH || BSDFD_T32_SPH_COND_SPLIT) {   // split-fp16: the lane's 11 values are K slots of two K = 16 chunks (the 16-query kernels' SPLIT_PRO)
                 const float e16[16] = {e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8], e[9], e[10], 0.f, 0.f, 0.f, 0.f, 0.f};
                 Frag eh[2], el[2];
                 split16(e16, eh, el);
@@ -410,6 +420,10 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
                 cacc = mfma32(wc.h1, el[1].v, cacc);
                 cacc = mfma32(wc.l0, eh[0].v, cacc);
                 cacc = mfma32(wc.l1, eh[1].v, cacc);
+                if (SPH) {   // the spherical term keeps the fourth product too (lo . lo)
+                    cacc = mfma32(wc.l0, el[0].v, cacc);
+                    cacc = mfma32(wc.l1, el[1].v, cacc);
+                }
             } else {      // exact fp32 chains (the spherical nets keep them: bsdfd.hip, SPLIT_PRO)
                 const float* Lwc = reinterpret_cast<const float*>(smem + LY::WC);
                 cacc = zero16;
@@ -585,12 +599,14 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
                     bt.p[0] = h ? wp : zero2; bt.p[1] = bt.p[0];
                     bt.p[2] = h ? -vp : zero2; bt.p[3] = bt.p[2];
                     zt1 = mfma32(a1, bt.v, zero16);
-                    const f32x4* Lwt0 = reinterpret_cast<const f32x4*>(smem + LY::WT0) + lane * 4;
+                    if (!BSDFD_T32_SPH_FOLD_T0) {
+                        const f32x4* Lwt0 = reinterpret_cast<const f32x4*>(smem + LY::WT0) + lane * 4;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const f32x4 t4 = Lwt0[k];
+                        for (int k = 0; k < 4; ++k) {
+                            const f32x4 t4 = Lwt0[k];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) zt0[4 * k + r] = t4[r];
+                            for (int r = 0; r < 4; ++r) zt0[4 * k + r] = t4[r];
+                        }
                     }
                 }
 #pragma unroll
@@ -601,15 +617,17 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
                     z = mm6<SPLIT>(w, bh, bl);
                     if constexpr (JAC) {
                         float t0v[16], t1v[16];
+                        const bool fold = BSDFD_T32_SPH_FOLD_T0 && layer == 0;   // W2 (g1 . W1[:, theta]) = F_theta g1
 #pragma unroll
                         for (int v = 0; v < 16; ++v) {
-                            t0v[v] = zt0[v] * gv[v];
+                            t0v[v] = fold ? gv[v] : zt0[v] * gv[v];
                             t1v[v] = zt1[v] * gv[v];
                         }
                         Frag t0h[2], t0l[2], t1h[2], t1l[2];
                         split16_jac(t0v, t0h, t0l);
                         split16_jac(t1v, t1h, t1l);
-                        mm6x2(w, t0h, t0l, w, t1h, t1l, zt0, zt1);
+                        if (fold) mm6x2(load_mat(smem, LY::WF, lane), t0h, t0l, w, t1h, t1l, zt0, zt1);
+                        else mm6x2(w, t0h, t0l, w, t1h, t1l, zt0, zt1);
                     }
                 }
                 if constexpr (JAC) { U0 = zt0; U1 = zt1; }
@@ -780,12 +798,12 @@ std::vector<char> build_image32_t(const bsdfd_desc& d) {
         for (int j = 0; j < 8; ++j) H(LY::A1)[(size_t)l * 8 + j] = f16_bits(s[j]);
 
     }
-    if (SPH)
+    if (SPH && !BSDFD_T32_SPH_FOLD_T0)
         for (int l = 0; l < 64; ++l)
             for (int v = 0; v < 16; ++v) F(LY::WT0)[(size_t)l * 16 + v] = w_in[(size_t)unit32(v, l >> 5) * IN + 0];
     // conditioning term: encoded value index ei (= 2 band + fn; 10 = the raw coordinate) of dimension hh
     auto pe_col = [&](int ei, int hh) { return ei < 10 ? SD + 1 + 2 + 4 * (ei >> 1) + 2 * (ei & 1) + hh : SD + 1 + hh; };
-    if (!SPH) {
+    if (!SPH || BSDFD_T32_SPH_COND_SPLIT) {
         for (int c = 0; c < 2; ++c)
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 8; ++j) {
@@ -804,6 +822,8 @@ std::vector<char> build_image32_t(const bsdfd_desc& d) {
         for (int i = 0; i < 2; ++i)   // F_i = W2 diag(W1[:, i]) (scaled layer-1 column)
             put_matrix(LY::WF + i * 4 * FR32,
                        [&](int row, int k) { return (double)d.w_hidden[(size_t)row * W + k] * (double)w_in[(size_t)k * IN + i]; });
+    else if (BSDFD_T32_SPH_FOLD_T0)   // F_theta = W2 diag(W1[:, theta])
+        put_matrix(LY::WF, [&](int row, int k) { return (double)d.w_hidden[(size_t)row * W + k] * (double)w_in[(size_t)k * IN + 0]; });
     for (int i = 0; i < 2; ++i)       // G_i[unit][k] = W_NH[k][unit] Wout[i][k] (Wout scaled by -ln 2)
         put_matrix(LY::WG + i * 4 * FR32, [&](int row, int k) {
             return (double)d.w_hidden[((size_t)(NH - 2) * W + k) * W + row] * (double)w_out[(size_t)i * W + k];
@@ -1022,8 +1042,472 @@ std::vector<char> build_image32w(const bsdfd_desc& d) {
     return img;
 }
 
-// which 32-query-tile kernel serves (net, precision, mode): 0 none, 1 flow_kernel32 (split3), 2 flow_kernel32w, 3 flow_kernel32 (f16)
+// ---------------------------------------------------------------------------------------------
+// The 64 x 6 spherical net WITH the Jacobian on 32-query tiles (round 6): NN_cond_pos_spherical_complicate,
+// rendering/utils/model.py:449-477 — the "64-wide" variant north_star asks the kernel to cover — in split-fp16 arithmetic, every call
+// that tracks the determinant (network_sampling / network_pdf / plugin sample / plugin pdf; mode 1).  Until round 5 this net ran on
+// 16-query tiles only (csrc/bsdfd.hip, FOLDOUT: 227 VGPRs, 0.146 of peak).
+//   * 64 units = two M-tiles of the 32x32 shape (as flow_kernel32w): lane (h, n) holds, for query n, units 32 mt + u(v, h) in z[mt][v];
+//     a 64 x 64 matrix = 2 x 2 blocks of 32 x 32, each 4 fragments (hi c0, hi c1, lo c0, lo c1) exactly like the 32-wide kernels'.
+//   * the Jacobian runs in plain FORWARD mode through all six layers, vector by vector: the activation, then d/dtheta, then d/dphi go
+//     through a layer's 16 fragments (12 MFMAs per block pair: 3 products x 2 K-chunks x 2 output M-tiles, alternating the two
+//     accumulators).  No folded matrices: the 16-query kernel's output fold buys it 1-2 % and costs 32 KB of LDS, which here holds
+//     the conditioning term instead;
+//   * d/dtheta of the layer-1 pre-activation is one more MFMA against the state fragment (B slots [1, 0, 1, 0, 0 ...] in the lower
+//     half-wave: W_hi + W_lo), d/dphi as in flow_kernel32; the output layer and its two tangent rows are fp32 VALU dots;
+//   * the conditioning term (32 registers per lane) lives in a per-wave LDS slab (8 KiB x 8 waves) next to the 92-KiB weight image:
+//     512 threads per workgroup, one workgroup per CU, 2 waves per SIMD.
+// Same io / segment / context / rng_index / row_index semantics as flow_kernel32 (spherical branch); base draws bit-identical.
+// ---------------------------------------------------------------------------------------------
+struct L32C {
+    static constexpr int NH = 6;
+    static constexpr int A1 = 0;                              // layer-1 state fragments of M-tile 0, 1
+    static constexpr int WC = A1 + 2 * FR32;                  // conditioning: 2 M-tiles x 11 x 64 floats (exact fp32 A operands)
+    static constexpr int WH = WC + 2 * 11 * 256;              // (NH - 1) matrices x blocks (mo, mi) x 4 fragments
+    static constexpr int WOUT = WH + (NH - 1) * 16 * FR32;    // 2 halves x 2 M-tiles x 16 x (Wout[0][u], Wout[1][u]) floats
+    static constexpr int BW1 = WOUT + 512;                    // base net, as L32
+    static constexpr int BB1 = BW1 + 7 * 256;
+    static constexpr int BW2 = BB1 + 64;
+    static constexpr int BB2 = BW2 + 256;
+    static constexpr int BW1S = BB2 + 16;
+    static constexpr int TOTAL = BW1S + 2 * FR32;
+    static constexpr int SLAB = 64 * 128;                     // per wave: the conditioning accumulators of both M-tiles
+    static constexpr int WAVES = 8;
+};
+
+__global__ __launch_bounds__(512, 2) void flow_kernel32c(const KParams p) {
+    using LY = L32C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (p.clk) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+    const char* img = p.img;
+    long long q_begin = 0, q_end = p.N;
+    int blk = blockIdx.x, nblk = gridDim.x, cl = p.chunk_log2;
+    int sidx = 0;
+    if (p.nseg > 0) {
+        for (int i = 1; i < p.nseg; ++i)
+            if ((int)blockIdx.x >= p.seg[i].blk_begin) sidx = i;
+        img = p.seg[sidx].img;
+        q_begin = p.seg[sidx].q_begin;
+        q_end = p.seg[sidx].q_end;
+        blk = blockIdx.x - p.seg[sidx].blk_begin;
+        nblk = p.seg[sidx].blk_end - p.seg[sidx].blk_begin;
+        cl = p.seg[sidx].chunk_log2;
+    }
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(img);
+        uint4* dst = reinterpret_cast<uint4*>(smem);
+        for (int i = threadIdx.x; i < LY::TOTAL / 16; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int lane0 = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: the tile index and everything derived from it stay in SGPRs)
+    const int waves_per_block = blockDim.x >> 6;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto uniform_f = [](float x) -> float { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(x))); };
+    auto uniform_d = [](double x) -> double {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    const double invT_d = uniform_d(1.0 / (double)p.T);
+    const bool t_pow2 = (p.T & (p.T - 1)) == 0;
+    const float invT = uniform_f((float)invT_d);
+    const bool reverse = (p.op == OP_PDF);
+    const float cstep = reverse ? -invT : invT;
+    const int op = p.op;
+    const long long ntiles = (q_end - q_begin + 31) / 32;
+    const long long chunk = (long long)waves_per_block << cl;
+    for (long long it = 0;; ++it) {
+        const long long chunk_base = ((it >> cl) * nblk + blk) * chunk;
+        if (chunk_base >= ntiles) break;
+        const long long tile = chunk_base + (it & ((1 << cl) - 1)) * waves_per_block + wave;
+        if (tile >= ntiles) continue;
+        auto opaque = [](int x) -> int { asm volatile("" : "+v"(x)); return x; };
+        const int lane = opaque(lane0);
+        const int h = lane >> 5;
+        const int n = lane & 31;
+        const long long tile_q0 = q_begin + tile * 32;
+        auto row_of = [&](int nn, bool& in_range) -> long long {
+            const long long r = tile_q0 + nn;
+            in_range = r < q_end;
+            return in_range ? r : q_end - 1;
+        };
+        bool in_range0;
+        const long long qi = row_of(n, in_range0);
+        auto user_row = [&](long long r) -> long long { return p.row_index ? p.row_index[r] : r; };
+        const long long qu = user_row(qi);
+
+        // ---------------- inputs (flow_kernel32, spherical branch) -------------------------------------
+        // (what the pdf epilogue needs of wi / wo — cos theta_i, cos theta_o, sin theta_o, the pole flag — is re-read there instead of
+        //  being carried across the Euler loop: the loop has no register to spare at 2 waves per SIMD)
+        float yh = 0.f;
+        float xs = 0.f;
+        float xo0 = 0.f, xo1 = 0.f;
+        const bool have_ctx = p.ctx_in != nullptr;
+        if (p.io == IO_OPERATOR) {
+            const float2 c2 = reinterpret_cast<const float2*>(p.in_a)[qi];
+            yh = h ? c2.y : c2.x;
+            if (p.op == OP_PDF || p.in_b != nullptr) {
+                const float2 b2 = reinterpret_cast<const float2*>(p.in_b)[qi];
+                xs = h ? b2.y : b2.x;
+                xo0 = b2.x; xo1 = b2.y;
+            }
+        } else {
+            const float wx = p.in_a[qu * 3 + 0], wy = p.in_a[qu * 3 + 1], wz = p.in_a[qu * 3 + 2];
+            if (!have_ctx) {
+                const SphArgs ai = spher_args(wx, wy, wz);  // rendering/brdf_measured_spherical.py:35-39
+                yh = atan2f(h ? ai.y : ai.s, h ? ai.x : ai.z);
+            }
+            if (p.op == OP_PDF) {
+                const float ox = p.in_b[qu * 3 + 0], oy = p.in_b[qu * 3 + 1], oz = p.in_b[qu * 3 + 2];
+                const SphArgs ao = spher_args(ox, oy, oz);
+                xs = atan2f(h ? ao.y : ao.s, h ? ao.x : ao.z);
+            } else if (p.in_b != nullptr) {  // injected base sample
+                const float2 b2 = reinterpret_cast<const float2*>(p.in_b)[qu];
+                xs = h ? b2.y : b2.x; xo0 = b2.x; xo1 = b2.y;
+            }
+        }
+
+        f32x16 cacc[2];
+        f32x4* const cslab = reinterpret_cast<f32x4*>(smem + LY::TOTAL + wave * LY::SLAB) + lane;   // [k][lane] f32x4, k = 4 mt + 0..3
+        f32x4 bo;
+        constexpr long long CTX_V4 = 8 * 64 + 32;  // f32x4 per tile: cacc (8 per lane) + bo per query
+        const long long ctx_slot = ((q_begin + tile * 32) >> 5) + p.seg_base + sidx;
+        if (have_ctx) {
+            const f32x4* c = reinterpret_cast<const f32x4*>(p.ctx_in) + ctx_slot * CTX_V4;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const f32x4 t4 = c[k * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cacc[k >> 2][4 * (k & 3) + r] = t4[r];
+            }
+            bo = c[8 * 64 + n];
+        } else {
+            float e[11];
+#pragma unroll
+            for (int b = 0; b < PE_BANDS; ++b) sincos_enc(yh * (float)(1 << b), e[2 * b], e[2 * b + 1]);
+            e[10] = yh;
+            // conditioning term c = W1[:, PE] PE(omega_i): exact fp32 chains, both M-tiles
+            const float* Lwc = reinterpret_cast<const float*>(smem + LY::WC);
+            cacc[0] = zero16; cacc[1] = zero16;
+#pragma unroll
+            for (int j = 0; j < 11; ++j) {
+                cacc[0] = mfma32f(Lwc[j * 64 + lane], e[j], cacc[0]);
+                cacc[1] = mfma32f(Lwc[(11 + j) * 64 + lane], e[j], cacc[1]);
+            }
+            // base-density net PE_3 -> 16 (SiLU) -> 4: as flow_kernel32
+            {
+                const f32x4* Lbb1 = reinterpret_cast<const f32x4*>(smem + LY::BB1 + h * 32);
+                const f32x4 b0 = Lbb1[0], b1 = Lbb1[1];
+                f32x16 bz = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const float b03[4] = {yh, e[0], e[1], e[2]}, b47[4] = {e[3], e[4], e[5], 0.0f};
+                Frag xh, xl;
+                split_pack<true>(b03, xh.p[0], xh.p[1], xl.p[0], xl.p[1]);
+                split_pack<true>(b47, xh.p[2], xh.p[3], xl.p[2], xl.p[3]);
+                const f16x8* Ls = reinterpret_cast<const f16x8*>(smem + LY::BW1S) + lane;
+                const f16x8 ah = Ls[0], al = Ls[64];
+                bz = mfma32(ah, xh.v, bz); bz = mfma32(ah, xl.v, bz); bz = mfma32(al, xh.v, bz); bz = mfma32(al, xl.v, bz);
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(bz));
+                const f32x4* Lbw2 = reinterpret_cast<const f32x4*>(smem + LY::BW2 + h * 128);
+                f32x4 po = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int v = 0; v < 8; ++v) po += silu(bz[v]) * Lbw2[v];
+                float o0 = po[0], o1 = po[1], o2 = po[2], o3 = po[3];
+                swap32(o0, o1);
+                swap32(o2, o3);
+                float s01 = o0 + o1, s23 = o2 + o3;
+                float a0, a1, a2, a3;
+                both32(s01, a0, a1);
+                both32(s23, a2, a3);
+                const f32x4 b2 = *reinterpret_cast<const f32x4*>(smem + LY::BB2);
+                bo = (f32x4){a0 + b2[0], a1 + b2[1], a2 + b2[2], a3 + b2[3]};
+            }
+            if (p.ctx_out != nullptr) {
+                f32x4* c = reinterpret_cast<f32x4*>(p.ctx_out) + ctx_slot * CTX_V4;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    c[k * 64 + lane] = (f32x4){cacc[k >> 2][4 * (k & 3)], cacc[k >> 2][4 * (k & 3) + 1], cacc[k >> 2][4 * (k & 3) + 2], cacc[k >> 2][4 * (k & 3) + 3]};
+                if (h == 0) c[8 * 64 + n] = bo;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            cslab[k * 64] = (f32x4){cacc[k >> 2][4 * (k & 3)], cacc[k >> 2][4 * (k & 3) + 1], cacc[k >> 2][4 * (k & 3) + 2], cacc[k >> 2][4 * (k & 3) + 3]};
+        auto kappa_of = [&]() -> float { return softplus(bo[3]) + 1e-3f; };   // (recomputed where needed, not carried)
+
+        // ---------------- initial state ------------------------------------------------------------
+        auto fexp = [](float x) -> float { return __builtin_amdgcn_exp2f(x * kLog2e); };
+        if (op == OP_SAMPLE && p.in_b == nullptr) {  // draw x0 ~ D_base(. | omega_i): same counters and arithmetic as the other kernels
+            const unsigned long long ctr = p.offset + (unsigned long long)(p.rng_index ? p.rng_index[qi] : qu);
+            const unsigned k0 = (unsigned)p.seed, k1 = (unsigned)(p.seed >> 32);
+            unsigned u[4];
+            philox4x32(k0, k1, (unsigned)ctr, (unsigned)(ctr >> 32), 0u, 0x476175u, u);  // "Gau"
+            const float rad = __builtin_amdgcn_sqrtf(-2.0f * kLn2 * __builtin_amdgcn_logf(u01_open(u[0])));
+            const float rev = u01_open(u[1]);
+            const float cs = __builtin_amdgcn_cosf(rev);
+            xo0 = bo[0] + rad * cs * (fexp(bo[1]) + 1e-3f);   // model.py:298-307
+            xo1 = von_mises_sample32(bo[2], kappa_of(), k0, k1, (unsigned)ctr, (unsigned)(ctr >> 32), lane);
+            xs = h ? xo1 : xo0;
+        }
+        auto base_pdf = [&](float a0, float a1) -> float {   // model.py:308-317
+            const float log2pi = 1.8378770664093453f;
+            const float e = (a0 - bo[0]) * __builtin_amdgcn_rcpf(fexp(bo[1]) + 1e-3f);
+            const float loggau = -0.5f * log2pi - bo[1] - 0.5f * e * e;
+            float sd_, cd_;
+            sincos_enc(a1 - bo[2], sd_, cd_);
+            const float kappa = kappa_of();
+            const float logvon = kappa * cd_ - log2pi - log_i0(kappa);
+            return fexp(loggau + logvon);
+        };
+        // ---------------- T explicit Euler steps ---------------------------------------------------
+        float acc = 1.0f;   // sampling: starts at p0 and is divided by every det — (p0 / det_1) / det_2 ... as the reference's tmp_J /= J
+        if (op == OP_SAMPLE) acc = base_pdf(xo0, xo1);
+        for (int t = 0; t < p.T; ++t) {
+            asm volatile("s_nop 0");   // keeps the weight-fragment loads inside the loop
+            float alpha;
+            if (t_pow2) {
+                const float tf = (float)t * invT;
+                alpha = reverse ? 1.0f - tf : tf;
+            } else {
+                const double tf = (double)t * invT_d;
+                alpha = (float)(reverse ? 1.0 - tf : tf);
+            }
+            float sp, cp;
+            sincos_enc(xs, sp, cp);   // (meaningful in the upper half, whose xs is phi)
+            const float vin = h ? sp : xs, win = h ? cp : alpha;
+            const float vh = hi_part(vin), wh = hi_part(win);
+            const f16x2 zero2 = {(_Float16)0.0f, (_Float16)0.0f}, one2 = {(_Float16)1.0f, (_Float16)0.0f};
+            const f16x2 vp = {(_Float16)vh, (_Float16)(vin - vh)}, wp = {(_Float16)wh, (_Float16)(win - wh)};
+            Frag b1, bt, bt0;
+            b1.p[0] = vp; b1.p[1] = vp; b1.p[2] = wp; b1.p[3] = wp;
+            // d(input)/dphi = (0, cos phi, -sin phi, 0) in the upper lanes; d(input)/dtheta = (1, 0, 0, 0) in the lower ones
+            bt.p[0] = h ? wp : zero2; bt.p[1] = bt.p[0]; bt.p[2] = h ? -vp : zero2; bt.p[3] = bt.p[2];
+            bt0.p[0] = h ? zero2 : one2; bt0.p[1] = bt0.p[0]; bt0.p[2] = zero2; bt0.p[3] = zero2;
+            const f16x8* La1 = reinterpret_cast<const f16x8*>(smem + LY::A1) + lane;
+            f32x16 z[2], zt0[2], zt1[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x16 cin;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 t4 = cslab[(4 * mt + k) * 64];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cin[4 * k + r] = t4[r];
+                }
+                const f16x8 a1 = La1[mt * 64];
+                z[mt] = mfma32(a1, b1.v, cin);
+                zt0[mt] = mfma32(a1, bt0.v, zero16);
+                zt1[mt] = mfma32(a1, bt.v, zero16);
+            }
+            // ---- hidden layers 1 .. NH-1: activation + the two tangents through W2 .. W_NH ----
+            // the three vectors (activation, d/dtheta, d/dphi) share every weight fragment: one 32 x 32 block at a time, 18 MFMAs
+            // round-robin over the three accumulators
+            // (the vector-by-vector order — each vector re-reading the 16 fragments — needs fewer registers and measured 5 % slower still)
+#pragma unroll 1
+            for (int layer = 0; layer < LY::NH - 1; ++layer) {
+                Frag hh[2][2], hl[2][2], ah[2][2], al[2][2], bh[2][2], bl[2][2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    float hv[16], gv[16], t0v[16], t1v[16];
+                    act16<true>(z[mt], hv, gv);
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        t0v[v] = zt0[mt][v] * gv[v];
+                        t1v[v] = zt1[mt][v] * gv[v];
+                    }
+                    split16(hv, hh[mt], hl[mt]);
+                    split16(t0v, ah[mt], al[mt]);
+                    split16(t1v, bh[mt], bl[mt]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mo = 0; mo < 2; ++mo) {
+                    f32x16 a = zero16, b = zero16, c = zero16;
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        const Mat32 w = load_mat(smem, LY::WH + ((layer * 2 + mo) * 2 + mi) * 4 * FR32, lane);
+                        a = mfma32(w.h0, hh[mi][0].v, a); b = mfma32(w.h0, ah[mi][0].v, b); c = mfma32(w.h0, bh[mi][0].v, c);
+                        a = mfma32(w.h1, hh[mi][1].v, a); b = mfma32(w.h1, ah[mi][1].v, b); c = mfma32(w.h1, bh[mi][1].v, c);
+                        a = mfma32(w.h0, hl[mi][0].v, a); b = mfma32(w.h0, al[mi][0].v, b); c = mfma32(w.h0, bl[mi][0].v, c);
+                        a = mfma32(w.h1, hl[mi][1].v, a); b = mfma32(w.h1, al[mi][1].v, b); c = mfma32(w.h1, bl[mi][1].v, c);
+                        a = mfma32(w.l0, hh[mi][0].v, a); b = mfma32(w.l0, ah[mi][0].v, b); c = mfma32(w.l0, bh[mi][0].v, c);
+                        a = mfma32(w.l1, hh[mi][1].v, a); b = mfma32(w.l1, ah[mi][1].v, b); c = mfma32(w.l1, bh[mi][1].v, c);
+                    }
+                    z[mo] = a; zt0[mo] = b; zt1[mo] = c;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- last hidden layer -> v and its two tangent rows: fp32 VALU dots over the lane's 32 units, then the lane pair ----
+            {
+                const f32x4* Lwo = reinterpret_cast<const f32x4*>(smem + LY::WOUT + h * 256);
+                f32x2 pv = {0.f, 0.f}, pd0 = pv, pd1 = pv;   // (v0, v1), d/dtheta of them, d/dphi of them
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    float hv[16], gv[16];
+                    act16<true>(z[mt], hv, gv);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const f32x4 w = Lwo[mt * 8 + k];
+                        const f32x2 w0 = {w[0], w[1]}, w1 = {w[2], w[3]};
+                        const float ta = zt0[mt][2 * k] * gv[2 * k], tb = zt0[mt][2 * k + 1] * gv[2 * k + 1];
+                        const float ua = zt1[mt][2 * k] * gv[2 * k], ub = zt1[mt][2 * k + 1] * gv[2 * k + 1];
+                        pv = __builtin_elementwise_fma((f32x2){hv[2 * k], hv[2 * k]}, w0, pv);
+                        pv = __builtin_elementwise_fma((f32x2){hv[2 * k + 1], hv[2 * k + 1]}, w1, pv);
+                        pd0 = __builtin_elementwise_fma((f32x2){ta, ta}, w0, pd0);
+                        pd0 = __builtin_elementwise_fma((f32x2){tb, tb}, w1, pd0);
+                        pd1 = __builtin_elementwise_fma((f32x2){ua, ua}, w0, pd1);
+                        pd1 = __builtin_elementwise_fma((f32x2){ub, ub}, w1, pd1);
+                    }
+                }
+                float pv0 = pv[0], pv1 = pv[1];
+                swap32(pv0, pv1);            // lower: v0 over the lane pair | upper: v1
+                xs = fmaf(cstep, pv0 + pv1, xs);
+                // J00 = dv0/dtheta, J11 = dv1/dphi, J01 = dv0/dphi, J10 = dv1/dtheta; det(I + c J) as in flow_kernel32
+                float ja = pd0[0], jb = pd1[1], jc = pd1[0], jd = pd0[1];
+                swap32(ja, jb);
+                const float sab = ja + jb;    // lower: J00 | upper: J11
+                swap32(jc, jd);
+                const float scd = jc + jd;    // lower: J01 | upper: J10
+                float w = fmaf(cstep, sab, 1.0f), o = cstep * scd;
+                swap32(w, o);                 // lower: (w00, w11) | upper: (o01, o10)
+                float pr = w * o, pr2 = pr;
+                swap32(pr, pr2);              // lower: pr = w00 w11, pr2 = o01 o10
+                const float det = pr - pr2;   // valid in the lower half (the lanes that write the results)
+                if (reverse) acc *= det; else acc *= __builtin_amdgcn_rcpf(det);
+            }
+        }
+
+        // ---------------- epilogue (flow_kernel32, spherical branch) ------------------------------------
+        float x0, x1;
+        both32(xs, x0, x1);
+        float pdf = 0.0f;
+        if (op == OP_SAMPLE) pdf = acc;
+        else if (op == OP_PDF) pdf = base_pdf(x0, x1) * acc;
+        bool valid_e;
+        const long long qe_tile = row_of(opaque(n), valid_e);
+        const long long qe = p.io == IO_OPERATOR ? qe_tile : user_row(qe_tile);
+        const bool writer = valid_e && (opaque(lane0) >> 5) == 0;
+        if (p.io == IO_OPERATOR) {
+            if (writer) {
+                if (op != OP_PDF) reinterpret_cast<float2*>(p.out_x)[qe] = make_float2(x0, x1);
+                p.out_pdf[qe] = pdf;
+            }
+        } else if (op == OP_SAMPLE) {  // rendering/brdf_measured_spherical.py:79-91, bsdf_myresult.py:69-84
+            float st, ct, sp, cp;
+            sincos_enc(x0, st, ct);
+            sincos_enc(x1, sp, cp);
+            if (!(st > 0.00005f)) pdf = 0.0f;
+            if (p.io == IO_PLUGIN && !(ct > 0.0f)) pdf = 0.0f;
+            const float ox = cp * st, oy = sp * st, oz = ct;
+            const float inv = fminf(fmaxf(1.0f / sqrtf(ox * ox + oy * oy), 1.0f), 3.402823466e+38f);
+            if (writer) {
+                p.out_x[qe * 3 + 0] = ox; p.out_x[qe * 3 + 1] = oy; p.out_x[qe * 3 + 2] = oz;
+                p.out_pdf[qe] = pdf * inv;
+            }
+        } else {
+            const float wi_z = p.in_a[qe * 3 + 2];
+            const float ox = p.in_b[qe * 3 + 0], oy = p.in_b[qe * 3 + 1], wo_z = p.in_b[qe * 3 + 2];
+            const float wo_sin = sqrtf(ox * ox + oy * oy);  // Mitsuba Frame3f::sin_theta
+            const bool wo_pole = spher_args(ox, oy, wo_z).ref_pole;
+            const float inv = fminf(fmaxf(1.0f / wo_sin, 1.0f), 3.402823466e+38f);
+            float pdf_sa;
+            if (p.io == IO_PLUGIN) {  // rendering/brdf_measured_spherical.py:122-137
+                if (wo_pole) pdf = 0.0f;
+                pdf_sa = (wi_z > 0.0f && wo_z > 0.0f) ? pdf * inv : 0.0f;
+            } else {                  // rendering/bsdf_myresult.py:115-133
+                pdf_sa = pdf * inv;
+            }
+            if (writer) p.out_pdf[qe] = pdf_sa;
+        }
+    }
+    if (p.clk) {
+        const unsigned long long dc = (unsigned long long)__builtin_readcyclecounter() - clk_c0;
+        const unsigned long long dr = (unsigned long long)__builtin_amdgcn_s_memrealtime() - clk_r0;
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long* slot = p.clk + 8 * ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (CLK_SLOTS - 1));
+            atomicAdd(slot, dc);
+            atomicAdd(slot + 1, dr);
+        }
+    }
+}
+
+std::vector<char> build_image32c(const bsdfd_desc& d) {
+    using LY = L32C;
+    constexpr int W = 64, NH = LY::NH, SD = 3, IN = SD + 1 + 2 + 4 * PE_BANDS, BIN = 2 + 4 * BASE_PE_BANDS;
+    std::vector<float> w_in((size_t)W * IN), w_out((size_t)2 * W);
+    for (size_t i = 0; i < w_in.size(); ++i) w_in[i] = (float)((double)d.w_in[i] * -1.4426950408889634);
+    for (size_t i = 0; i < w_out.size(); ++i) w_out[i] = (float)((double)d.w_out[i] * -0.6931471805599453);
+    std::vector<char> img(LY::TOTAL, 0);
+    auto F = [&](int o) { return reinterpret_cast<float*>(img.data() + o); };
+    auto H = [&](int o) { return reinterpret_cast<uint16_t*>(img.data() + o); };
+    auto pe_col = [&](int ei, int hh) { return ei < 10 ? SD + 1 + 2 + 4 * (ei >> 1) + 2 * (ei & 1) + hh : SD + 1 + hh; };
+    for (int mt = 0; mt < 2; ++mt)
+        for (int l = 0; l < 64; ++l) {
+            const int hh = l >> 5, row = 32 * mt + (l & 31);
+            // layer-1 state fragment: slots [Wv_hi, Wv_hi, Wv_lo, Wv_lo, Ww_hi, Ww_hi, Ww_lo, Ww_lo]; columns [theta, sin phi, cos phi, alpha]
+            const float wv = w_in[(size_t)row * IN + (hh == 0 ? 0 : 1)], ww = w_in[(size_t)row * IN + (hh == 0 ? 3 : 2)];
+            const float sl[8] = {f16_rnd(wv), f16_rnd(wv), wv - f16_rnd(wv), wv - f16_rnd(wv), f16_rnd(ww), f16_rnd(ww), ww - f16_rnd(ww), ww - f16_rnd(ww)};
+            for (int j = 0; j < 8; ++j) H(LY::A1)[(size_t)(mt * 64 + l) * 8 + j] = f16_bits(sl[j]);
+            for (int j = 0; j < 11; ++j) F(LY::WC)[(size_t)(mt * 11 + j) * 64 + l] = w_in[(size_t)row * IN + pe_col(j, hh)];
+        }
+    // hidden matrices: block (mo, mi) = rows 32 mo .., K units 32 mi + u(8 c + j, hh): 4 fragments (hi c0, hi c1, lo c0, lo c1)
+    for (int layer = 0; layer < NH - 1; ++layer)
+        for (int mo = 0; mo < 2; ++mo)
+            for (int mi = 0; mi < 2; ++mi) {
+                const int off = LY::WH + ((layer * 2 + mo) * 2 + mi) * 4 * FR32;
+                for (int c = 0; c < 2; ++c)
+                    for (int l = 0; l < 64; ++l)
+                        for (int j = 0; j < 8; ++j) {
+                            const int hh = l >> 5, row = 32 * mo + (l & 31), k = 32 * mi + unit32(8 * c + j, hh);
+                            const float v = d.w_hidden[((size_t)layer * W + row) * W + k];
+                            H(off)[(size_t)(c * 64 + l) * 8 + j] = f16_bits(v);
+                            H(off)[(size_t)((2 + c) * 64 + l) * 8 + j] = f16_bits(v - f16_rnd(v));
+                        }
+            }
+    for (int hh = 0; hh < 2; ++hh)
+        for (int mt = 0; mt < 2; ++mt)
+            for (int v = 0; v < 16; ++v) {
+                const int u = 32 * mt + unit32(v, hh);
+                F(LY::WOUT)[hh * 64 + mt * 32 + 2 * v] = w_out[u];
+                F(LY::WOUT)[hh * 64 + mt * 32 + 2 * v + 1] = w_out[W + u];
+            }
+    // base net: as build_image32_t
+    for (int j = 0; j < 7; ++j)
+        for (int l = 0; l < 64; ++l) {
+            const int hh = l >> 5, row = l & 31;
+            const int col = j == 0 ? hh : 2 + 4 * ((j - 1) >> 1) + 2 * ((j - 1) & 1) + hh;
+            F(LY::BW1)[(size_t)j * 64 + l] = row < BASE_HIDDEN ? d.base_w1[(size_t)row * BIN + col] : 0.0f;
+        }
+    for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+            const int hh = l >> 5, row = l & 31;
+            const int col = j == 0 ? hh : 2 + 4 * ((j - 1) >> 1) + 2 * ((j - 1) & 1) + hh;
+            const float w = (j < 7 && row < BASE_HIDDEN) ? d.base_w1[(size_t)row * BIN + col] : 0.0f;
+            H(LY::BW1S)[(size_t)l * 8 + j] = f16_bits(w);
+            H(LY::BW1S)[(size_t)(64 + l) * 8 + j] = f16_bits(w - f16_rnd(w));
+        }
+    for (int hh = 0; hh < 2; ++hh)
+        for (int v = 0; v < 8; ++v) {
+            F(LY::BB1)[hh * 8 + v] = d.base_b1[unit32(v, hh)];
+            for (int j = 0; j < 4; ++j) F(LY::BW2)[(hh * 8 + v) * 4 + j] = d.base_w2[(size_t)j * BASE_HIDDEN + unit32(v, hh)];
+        }
+    for (int j = 0; j < 4; ++j) F(LY::BB2)[j] = d.base_b2[j];
+    return img;
+}
+
+// which 32-query-tile kernel serves (net, precision, mode): 0 none, 1 flow_kernel32 (split3), 2 flow_kernel32w, 3 flow_kernel32 (f16),
+// 4 flow_kernel32c (the 64 x 6 spherical net in split3 with the Jacobian: mode 1 only — its samples-only and fused calls stay on
+// 16-query tiles).  Kind 4 is OPT-IN (bsdfd_desc.tile = 32 explicitly; bsdfd_kernel32_opt_in): measured 4 % slower than the 16-query
+// kernel — 4 % fewer shader cycles at a 7.5 % lower clock, +2.5 % J/query (profiles/r06_ab/ab32c_64x6_jacobian.txt) — the library's
+// default for this net stays the 16-query kernel.
+#ifndef BSDFD_T32_WIDE_JAC
+#define BSDFD_T32_WIDE_JAC 1   // 0: flow_kernel32c not offered at all (A/B builds)
+#endif
 int kind32(const bsdfd_desc& d, int prec, int mode) {
+    if (BSDFD_T32_WIDE_JAC && prec == BSDFD_PREC_SPLIT3 && d.width == 64 && d.n_hidden == 6 && d.domain == BSDFD_DOMAIN_SPHERICAL && mode == 1)
+        return 4;
     if (prec == BSDFD_PREC_SPLIT3 && d.width == 32 &&
         ((d.domain == BSDFD_DOMAIN_DISK && d.n_hidden == 3) || (d.domain == BSDFD_DOMAIN_SPHERICAL && d.n_hidden == 4)))
         return 1;
@@ -1040,13 +1524,21 @@ bool bsdfd_tile32_supported(const bsdfd_desc& d, int prec) {
     return kind32(d, prec, 0) != 0 || kind32(d, prec, 1) != 0;
 }
 
+bool bsdfd_kernel32_opt_in(const bsdfd_desc& d, int prec, int mode) { return kind32(d, prec, mode) == 4; }
+
+int bsdfd_tile32_context_v4(const bsdfd_desc& d, int prec) {   // f32x4 records per 32-query tile of the per-query context (mode 1)
+    return kind32(d, prec, 1) == 4 ? 8 * 64 + 32 : 4 * 64 + 32;
+}
+
 
 std::vector<char> bsdfd_build_image32(const bsdfd_desc& d, int prec) {
+    if (kind32(d, prec, 1) == 4) return build_image32c(d);
     if (kind32(d, prec, 0) == 2) return build_image32w(d);
     return d.domain == BSDFD_DOMAIN_DISK ? build_image32_t<BSDFD_DOMAIN_DISK>(d) : build_image32_t<BSDFD_DOMAIN_SPHERICAL>(d);
 }
 
 int bsdfd_kernel32_lds_bytes(const bsdfd_desc& d, int prec, int mode) {
+    if (kind32(d, prec, mode) == 4) return L32C::TOTAL + L32C::WAVES * L32C::SLAB;
     if (kind32(d, prec, mode) == 2) return L32W::TOTAL;
     const int domain = d.domain;   // (kind 3 = mode 0 of the same kernel template: same image, same slab)
     if (mode == 2)
@@ -1056,10 +1548,14 @@ int bsdfd_kernel32_lds_bytes(const bsdfd_desc& d, int prec, int mode) {
                                        : L32<BSDFD_DOMAIN_SPHERICAL>::TOTAL + 4 * CaccLds<BSDFD_DOMAIN_SPHERICAL, false>::slab;
 }
 
-int bsdfd_kernel32_threads(const bsdfd_desc& d, int prec, int mode) { return kind32(d, prec, mode) == 2 ? 512 : 256; }
+int bsdfd_kernel32_threads(const bsdfd_desc& d, int prec, int mode) {
+    const int kind = kind32(d, prec, mode);
+    return (kind == 2 || kind == 4) ? 512 : 256;
+}
 
 const void* bsdfd_kernel32(const bsdfd_desc& d, int prec, int mode) {
     const int kind = kind32(d, prec, mode);
+    if (kind == 4) return reinterpret_cast<const void*>(flow_kernel32c);
     if (kind == 2) return reinterpret_cast<const void*>(flow_kernel32w);
     const bool disk = d.domain == BSDFD_DOMAIN_DISK;
     if (kind == 3)

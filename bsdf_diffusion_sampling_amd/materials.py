@@ -478,11 +478,22 @@ class WavefrontPipeline:
     ``push()`` returns a ``_Wavefront``; at most two are in flight: the buffers of wavefront k are reused by wavefront k+2,
     so take ``result()`` of a wavefront before pushing the second one after it."""
 
-    def __init__(self, table: MaterialTable, direct: bool = True):
-        """``direct`` (default since round 6): the flow kernels read ``wi`` and write the results in lane order through the bucket
-        permutation (``bsdfd_opts.row_index``) — only the bucketing itself (count, scan, permutation) is left on the side stream,
-        the gather of ``wi`` and the scatter of (wo, pdf, pdf) are gone.  ``direct=False``: the round-4 form (gather on the side
-        stream, bucket-ordered launches, scatter on a third stream); identical results."""
+    # Largest wavefront (lanes) served through the bucket permutation when ``direct`` is left to the pipeline.  Measured, 52 materials,
+    # steady state, alternating (profiles/r06_ab/mixed_row_index_vs_gather_by_size.jsonl): wall time of the direct form over the
+    # gather form 0.92 (256 Ki lanes), 0.97 (1 Mi), 1.00 (2 Mi), 0.93 (4 Mi), 0.95 (8 Mi), 1.05 (16 Mi).  Why it turns: a row-indexed
+    # 12-byte access touches a whole line that ~10 tiles of OTHER buckets touch at other times; while the lane-ordered arrays sit in
+    # the 256 MiB Infinity Cache that is free, beyond it every touch is an HBM access — at 16 Mi lanes the direct form moves 8.7 GB
+    # per wavefront on the HBM side against 6.1 GB (1.07 GB algorithmic; rocprofv3 FETCH_SIZE / WRITE_SIZE,
+    # profiles/r06_ab/mixed_16Mi_row_index_vs_gather_pmc.json): it reads wi through the index twice and writes AND re-reads wo through
+    # it, the gather form pays each amplified pass once.
+    DIRECT_MAX_LANES = 8 << 20
+
+    def __init__(self, table: MaterialTable, direct: Optional[bool] = None):
+        """``direct``: the flow kernels read ``wi`` and write the results in lane order through the bucket permutation
+        (``bsdfd_opts.row_index``, round 6) — only the bucketing itself (count, scan, permutation) is left on the side stream, the
+        gather of ``wi`` and the scatter of (wo, pdf, pdf) are gone.  ``False``: the round-4 form (gather on the side stream,
+        bucket-ordered launches, scatter on a third stream).  ``None`` (default): by wavefront size — direct up to
+        ``DIRECT_MAX_LANES`` lanes, the gather form beyond.  Identical results either way, bit for bit."""
         self.tab = table
         self.direct = direct
         self.pre = self.post = None
@@ -499,6 +510,7 @@ class WavefrontPipeline:
         * a ``torch.cuda.Event`` the producer recorded right behind its last write (e.g. on its own stream): full overlap;
         * ``False``: the inputs are complete already (resident arrays, a host-synchronised producer): no wait at all."""
         tab, dev = self.tab, wi.device
+        direct = self.direct if self.direct is not None else wi.shape[0] <= self.DIRECT_MAX_LANES
         main = torch.cuda.current_stream(dev)
         if self.pre is None or self.pre.device != dev:
             self.pre, self.post = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
@@ -512,14 +524,16 @@ class WavefrontPipeline:
             if w.flow_done is not None:
                 self.pre.wait_event(w.flow_done)       # the flow kernels of wavefront k-2 have read the buffers reused here
             plan = tab.bucket(material_id, extra_bins)  # (the host waits for the counts on THIS stream only)
-            wi_b = None if self.direct else tab.gather(plan, wi)
+            wi_b = None if direct else tab.gather(plan, wi)
             for t in (plan[0], wi_b):
                 if t is not None:
                     t.record_stream(main)
             w.plan, w.wi_b = plan, wi_b
             w.prep_done = self.pre.record_event()
         main.wait_event(w.prep_done)
-        if self.direct:
+        if direct:
+            if w.scatter_done is not None:
+                main.wait_event(w.scatter_done)   # (a slot last used by the gather form: its scatter reads the slot's buffers)
             wo, pdf = tab.sample(plan, wi, seed=seed, offset=offset, ctx=ctx, direct=True)
             p2 = tab.pdf(plan, wi, wo, ctx=ctx, direct=True)
             w.bucketed = None

@@ -329,7 +329,11 @@ class ArrayRenderer(WavefrontRenderer):
         offset = row_begin * self.camera.width * spp
         skey = (seed * 0x9E3779B97F4A7C15 + pass_idx + 1) & 0xFFFFFFFFFFFFFFFF
         if not self.use_ground_truth:
-            b["wo"], b["pdf_o"], b["pdf_l"] = self.table.sample_pdf(plan, b["wi"], b["wl"], seed=skey, offset=offset)
+            # (through the bucket permutation — no gathered copies of wi / wl, no scatter of the three results — while the pass's
+            #  arrays fit the Infinity Cache: materials.WavefrontPipeline.DIRECT_MAX_LANES; the same numbers bit for bit)
+            from .materials import WavefrontPipeline
+            b["wo"], b["pdf_o"], b["pdf_l"] = self.table.sample_pdf(plan, b["wi"], b["wl"], seed=skey, offset=offset,
+                                                                    direct=n <= WavefrontPipeline.DIRECT_MAX_LANES)
         else:
             # ground truth where a tensor file exists, evaluated on the bucket-ordered arrays (a material's rows
             # are contiguous there); NaN = "no ground truth for this path" -> the shade kernel uses the proxy

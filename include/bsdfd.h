@@ -89,9 +89,12 @@ typedef struct bsdfd_desc {
                              * 16x16x32-MFMA kernels (every net), 32 = the 32x32x16-MFMA kernels, which exist for
                              *   (1) the reference's two plugin nets — disk 32x3, spherical 32x4 — in BSDFD_PREC_SPLIT3 (all calls),
                              *   (2) bsdfd_flow_samples_only of the 64 x 6 spherical teacher in BSDFD_PREC_F16,
-                             *   (3) bsdfd_flow_samples_only of those two 32-wide nets in BSDFD_PREC_F16.
+                             *   (3) bsdfd_flow_samples_only of those two 32-wide nets in BSDFD_PREC_F16,
+                             *   (4) the Jacobian calls (sampling / pdf, operator and plugin level) of the 64 x 6 spherical net in
+                             *       BSDFD_PREC_SPLIT3 — OPT-IN: served only when 32 is asked for explicitly (it measured 4 % slower
+                             *       than the 16-query kernel, which stays this net's default).
                              * An explicit 32 for a (net, precision) with no such kernel at all is REJECTED by bsdfd_create
-                             * (BSDFD_EINVAL); where only some calls have one — (2), (3) — the others run 16-query tiles and
+                             * (BSDFD_EINVAL); where only some calls have one — (2), (3), (4) — the others run 16-query tiles and
                              * bsdfd_get_tile says which.  Product behaviour depends on this field alone: the library reads
                              * no environment variable (the Python hosts map $BSDFD_TILE onto it for A/B runs).
                              * Both tilings implement the same operators to the same tolerance.  Was `reserved` before ABI 5:

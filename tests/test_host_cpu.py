@@ -367,8 +367,8 @@ def test_asynchronous_lds_reads_are_not_touched_before_their_wait():
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(", 0 violations") == 8 and "25 asynchronous" in r.stdout and "21 asynchronous" in r.stdout
     assert "census of the two translation units: 0 problem(s)" in r.stdout
-    assert "MFMA results consumed before their wait states: 0 of 63 kernels" in r.stdout
-    assert "lane swaps of a register written fewer than 2 wait states earlier: 0 of 63 kernels" in r.stdout
+    assert "MFMA results consumed before their wait states: 0 of 64 kernels" in r.stdout
+    assert "lane swaps of a register written fewer than 2 wait states earlier: 0 of 64 kernels" in r.stdout
     assert r.stdout.count("occupancy ") == 9 and "LOST" not in r.stdout, r.stdout   # waves/SIMD of the tracked kernels
 
 
@@ -501,12 +501,12 @@ def test_assembly_census_fails_closed(tmp_path):
     paths = _product_asm()
     assert A.verify_census(paths, "async") == []
     exp = A.expected_flow_kernels("async")
-    assert len(exp) == 63 and sum(1 for v in exp.values() if v["async"]) == 8      # 54 in csrc/bsdfd.hip + 9 in csrc/flow32.hip
+    assert len(exp) == 64 and sum(1 for v in exp.values() if v["async"]) == 8      # 54 in csrc/bsdfd.hip + 10 in csrc/flow32.hip
     assert all((v["async"], v["waits"]) == (0, 0) for v in A.expected_flow_kernels("plain").values())
     assert sum(1 for v in exp.values() if v.get("sel")) == 3 + 7                    # the packed-fp16 sigmoids (inline-asm SDWA halves)
     empty = tmp_path / "empty.s"
     empty.write_text("")
-    assert len(A.verify_census([str(empty)], "async")) == 63                        # (a) nothing found
+    assert len(A.verify_census([str(empty)], "async")) == 64                        # (a) nothing found
     text = open(paths[0]).read()
     renamed = tmp_path / "renamed.s"
     renamed.write_text(text.replace("flow_kernel", "flowkernel"))
