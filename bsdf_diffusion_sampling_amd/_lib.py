@@ -11,7 +11,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.environ.get("BSDFD_LIB_PATH") or os.path.join(_HERE, "libbsdfd.so")  # override: A/B builds
+DEFAULT_LIB_PATH = os.path.join(_HERE, "libbsdfd.so")
+LIB_PATH = os.environ.get("BSDFD_LIB_PATH") or DEFAULT_LIB_PATH  # override: A/B builds
 SRC_PATH = os.path.join(_HERE, "csrc", "bsdfd.hip")
 SRC32_PATH = os.path.join(_HERE, "csrc", "flow32.hip")   # the 32-query-tile flow kernels
 SRC_PATHS = [SRC_PATH, SRC32_PATH, os.path.join(_HERE, "csrc", "wavefront.hip"), os.path.join(_HERE, "csrc", "encoding.hip"),
@@ -265,12 +266,6 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
             info["unverified"] = True
             extra = ["-DBSDFD_UNVERIFIED_BUILD"] + (["-DBSDFD_NO_ASYNC_LDS"] if info["variant"] == "plain" else [])
             _compile_flow_tu(td, extra, verbose)   # the marker goes into bsdfd_version()
-        if out == LIB_PATH and not fatal:
-            # the verified assembly of the product build, kept for tools/isa_mix.py and the census tests (build/ is scratch)
-            import shutil
-            os.makedirs(ASM_CACHE_DIR, exist_ok=True)
-            for a in asms:
-                shutil.copyfile(a, os.path.join(ASM_CACHE_DIR, os.path.basename(a).split("-hip-")[0] + ".s"))
         cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", os.path.join(td, "bsdfd.o"), *side, "-o", tmp]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -281,6 +276,19 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
                 json.dump(info, f, indent=1)
             os.replace(f"{out}.build.json.tmp.{os.getpid()}", out + ".build.json")
             os.replace(tmp, out)
+            if os.path.abspath(out) == DEFAULT_LIB_PATH and not fatal:
+                # the verified assembly of the library that is NOW in place, kept for tools/isa_mix.py and the census tests (build/ is
+                # scratch; a read-only tree must not fail the build).  Only for the default product path — never for an A/B library
+                # selected with $BSDFD_LIB_PATH — and stamped with the kernel sources' hash, which the readers compare.
+                try:
+                    import shutil
+                    os.makedirs(ASM_CACHE_DIR, exist_ok=True)
+                    for a in asms:
+                        shutil.copyfile(a, os.path.join(ASM_CACHE_DIR, os.path.basename(a).split("-hip-")[0] + ".s"))
+                    with open(os.path.join(ASM_CACHE_DIR, "source.sha256"), "w") as f:
+                        f.write(kernel_source_sha256() + "\n")
+                except OSError as exc:
+                    print(f"bsdfd build: could not cache the verified assembly under {ASM_CACHE_DIR}: {exc}", flush=True)
         finally:
             for leftover in (tmp, f"{out}.build.json.tmp.{os.getpid()}"):
                 if os.path.exists(leftover):
@@ -289,6 +297,17 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
         print(f"bsdfd build: shipped the {'asynchronous-LDS' if info['variant'] == 'async' else 'FALLBACK (compiler-managed LDS)'} "
               f"variant of the flow kernels ({out})", flush=True)
     return out
+
+
+def cached_asm_paths():
+    """[bsdfd.s, flow32.s] under build/asm/ if that cache is the assembly of the CURRENT kernel sources (hash stamp written by
+    ``build()``), else None — the readers (tools/isa_mix.py, the census tests) rebuild instead of trusting file times."""
+    paths = [os.path.join(ASM_CACHE_DIR, f) for f in ("bsdfd.s", "flow32.s")]
+    try:
+        stamp = open(os.path.join(ASM_CACHE_DIR, "source.sha256")).read().strip()
+    except OSError:
+        return None
+    return paths if stamp == kernel_source_sha256() and all(os.path.exists(q) for q in paths) else None
 
 
 def build_info(lib_path: str = None) -> dict:

@@ -486,9 +486,11 @@ def _product_asm():
     if not shutil.which("hipcc"):
         pytest.skip("needs hipcc")
     from bsdf_diffusion_sampling_amd import _lib
-    paths = [os.path.join(_lib.ASM_CACHE_DIR, f) for f in ("bsdfd.s", "flow32.s")]
-    if not all(os.path.exists(q) and os.path.getmtime(q) >= os.path.getmtime(_lib.LIB_PATH) - 600 for q in paths):
-        _lib.build(force=True)
+    paths = _lib.cached_asm_paths()   # None unless the cache carries the hash of the current kernel sources
+    if paths is None:
+        _lib.build(force=True, lib_path=_lib.DEFAULT_LIB_PATH)
+        paths = _lib.cached_asm_paths()
+    assert paths is not None, "build() did not leave the verified assembly of the current sources under build/asm/"
     return paths
 
 
