@@ -84,6 +84,7 @@ def test_plugin_calls_agree_with_the_16_query_kernel(n):
         ok = np.abs(b_) > 1e-6 * max(np.abs(b_).max(), 1e-300)
         rel = np.abs(a_ - b_)[ok] / np.abs(b_[ok])
         return bool(np.isfinite(a_).all() and ((a_ == 0) == (b_ == 0)).all() and (rel.size == 0 or (np.median(rel) < 1e-4 and rel.max() < 5e-2)))
+    from test_gpu_tilings import same_dirs   # (two fp32 evaluation orders: median <= 1e-5, at most 0.2 % of the rows beyond 1e-4)
     g, fw = load_case("aniso_miro_7_rgb_spherical_complex")
     s32, s16 = _pair(fw)
     rng = np.random.default_rng(n)
@@ -94,7 +95,7 @@ def test_plugin_calls_agree_with_the_16_query_kernel(n):
     for variant in (0, 1):
         wo, p = s32.plugin_sample(wi, None, T=8, variant=variant, seed=5, offset=77)
         wo16, p16 = s16.plugin_sample(wi, None, T=8, variant=variant, seed=5, offset=77)
-        assert torch.allclose(wo, wo16, rtol=0, atol=1e-4)
+        assert same_dirs(wo, wo16), (wo - wo16).abs().max().item()
         assert same_density(p, p16)
         pl, pl16 = s32.plugin_pdf(wi, wl, T=8, variant=variant), s16.plugin_pdf(wi, wl, T=8, variant=variant)
         assert same_density(pl, pl16)
