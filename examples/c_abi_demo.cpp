@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "bsdfd.h"
@@ -99,6 +100,46 @@ int main(int argc, char** argv) {
     for (long long i = 0; i < n; ++i) diff_ctx += pp3[i] != pp[i];
     std::printf("ctx   : %lld B of per-query context; %lld of %lld pdf values differ from the eager run\n", ctx_bytes, diff_ctx, n);
     HIPCHECK(hipFree(d_ctx));
+
+    // ABI 6 — bsdfd_opts.row_index: a wavefront whose lanes carry a material tag is bucketed on the device
+    // (bsdfd_bucket_by_material) and the flow kernel reads wi / writes (wo, pdf) in LANE order through the bucket permutation:
+    // no gathered copy, no scatter.  Here: two "materials" served by the same handle, lanes tagged 0 / 1 / 2 (2 = no material);
+    // the lanes of material 0 must come out exactly as in the plain run above (Philox counter = offset + lane), the lanes of
+    // tag 2 untouched.
+    long long diff_row = 0, untouched_bad = 0;
+    if (bsdfd_abi_version() != BSDFD_ABI_VERSION) { std::fprintf(stderr, "ABI mismatch\n"); return 1; }
+    {
+        std::vector<long long> ids(n);
+        for (long long i = 0; i < n; ++i) ids[i] = (i * 2654435761ull >> 7) % 3;
+        long long *d_ids = nullptr, *d_perm = nullptr, *d_counts = nullptr;
+        void* d_ws = nullptr;
+        const long long ws_bytes = bsdfd_bucket_workspace_bytes(n, 3);
+        HIPCHECK(hipMalloc(&d_ids, 8 * n)); HIPCHECK(hipMalloc(&d_perm, 8 * n)); HIPCHECK(hipMalloc(&d_counts, 8 * 3));
+        HIPCHECK(hipMalloc(&d_ws, (size_t)ws_bytes));
+        HIPCHECK(hipMemcpy(d_ids, ids.data(), 8 * n, hipMemcpyHostToDevice));
+        CHECK(bsdfd_bucket_by_material(reinterpret_cast<const int64_t*>(d_ids), n, 3, reinterpret_cast<int64_t*>(d_perm),
+                                       reinterpret_cast<int64_t*>(d_counts), d_ws, ws_bytes, st));
+        long long counts[3];
+        HIPCHECK(hipMemcpyAsync(counts, d_counts, sizeof counts, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        const int64_t seg_end[2] = {counts[0], counts[0] + counts[1]};   // buckets 0 and 1 carry a material, bucket 2 does not
+        const bsdfd_handle hs[2] = {h, h};
+        HIPCHECK(hipMemsetAsync(d_wo, 0xff, 12 * n, st)); HIPCHECK(hipMemsetAsync(d_ps, 0xff, 4 * n, st));
+        bsdfd_opts orow = {};
+        orow.row_index = reinterpret_cast<const int64_t*>(d_perm);
+        CHECK(bsdfd_plugin_sample_multi_ex(hs, 2, seg_end, BSDFD_PLUGIN_MEASURED, d_wi, nullptr, 7, 0, T, d_wo, d_ps, &orow, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        std::vector<float> ps4(n);
+        HIPCHECK(hipMemcpy(ps4.data(), d_ps, 4 * n, hipMemcpyDeviceToHost));
+        for (long long i = 0; i < n; ++i) {
+            unsigned bits; std::memcpy(&bits, &ps4[i], 4);
+            if (ids[i] == 2) untouched_bad += bits != 0xffffffffu;
+            else diff_row += ps4[i] != ps[i];
+        }
+        std::printf("rows  : %lld + %lld lanes through bsdfd_opts.row_index; %lld pdf values differ from the plain run, %lld untagged lanes touched\n",
+                    (long long)counts[0], (long long)counts[1], diff_row, untouched_bad);
+        HIPCHECK(hipFree(d_ids)); HIPCHECK(hipFree(d_perm)); HIPCHECK(hipFree(d_counts)); HIPCHECK(hipFree(d_ws));
+    }
     bsdfd_destroy(h);
-    return diff == 0 && diff_ctx == 0 && pos > n / 2 && norm_err < 1e-4 ? 0 : 1;
+    return diff == 0 && diff_ctx == 0 && diff_row == 0 && untouched_bad == 0 && pos > n / 2 && norm_err < 1e-4 ? 0 : 1;
 }

@@ -25,6 +25,7 @@ def test_c_abi_demo_builds_and_runs(tmp_path):
         assert r.returncode == 0, r.stdout + r.stderr
         assert "graph : 0 of 200000 pdf values differ" in r.stdout, r.stdout
         assert "of per-query context; 0 of 200000 pdf values differ" in r.stdout, r.stdout   # bsdfd_opts / *_ex from plain C++
+        assert "row_index; 0 pdf values differ from the plain run, 0 untagged lanes touched" in r.stdout, r.stdout   # ABI 6
     r = subprocess.run([exe, "/nonexistent.bsdfw"], capture_output=True, text=True)
     assert r.returncode != 0 and "cannot open" in r.stderr
 

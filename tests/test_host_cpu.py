@@ -89,6 +89,39 @@ def test_header_is_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr
 
 
+def test_ctypes_structs_mirror_the_header(tmp_path):
+    """The ctypes mirrors of the boundary's structs (bsdf_diffusion_sampling_amd/_lib.py: Desc, Opts, WfScene) have the size and
+    the field offsets gcc gives the C declarations of include/bsdfd.h, and the host's ABI_VERSION is the header's
+    BSDFD_ABI_VERSION (structs grow at the end between versions: a stale mirror would pass garbage for the new fields)."""
+    import ctypes as C
+    import shutil
+    if not shutil.which("gcc"):
+        pytest.skip("needs gcc")
+    from bsdf_diffusion_sampling_amd import _lib
+    fields = {"bsdfd_desc": [n for n, _ in _lib.Desc._fields_], "bsdfd_opts": [n for n, _ in _lib.Opts._fields_],
+              "bsdfd_wf_scene": [n for n, _ in _lib.WfScene._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "bsdfd.h"', 'int main(void) {', '  printf("abi %d\\n", BSDFD_ABI_VERSION);']
+    for st, names in fields.items():
+        src.append(f'  printf("{st} size %zu\\n", sizeof({st}));')
+        for f in names:
+            src.append(f'  printf("{st} {f} %zu\\n", offsetof({st}, {f}));')
+    src += ['  return 0;', '}']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    got = {}
+    for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines():
+        parts = line.split()
+        got[tuple(parts[:-1])] = int(parts[-1])
+    assert got[("abi",)] == _lib.ABI_VERSION
+    for st, cls in (("bsdfd_desc", _lib.Desc), ("bsdfd_opts", _lib.Opts), ("bsdfd_wf_scene", _lib.WfScene)):
+        assert got[(st, "size")] == C.sizeof(cls), st
+        for f in fields[st]:
+            assert got[(st, f)] == getattr(cls, f).offset, (st, f)
+    assert [n for n, _ in _lib.Opts._fields_] == ["ctx_out", "ctx_in", "rng_index", "row_index"]
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly without the GPU / the HIP library."""
     if torch.cuda.is_available():
