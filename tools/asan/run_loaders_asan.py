@@ -27,7 +27,7 @@ def main():
     exe = os.path.join(tmp, "loaders_asan")
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O1", "-g", "-std=c++17", SAN, "-fno-gpu-sanitize", "-fno-omit-frame-pointer",
                     "-Wno-unused-value", "-Wno-pass-failed", "-I", os.path.join(ROOT, "include"), os.path.join(csrc, "measured.hip"),
-                    os.path.join(csrc, "bsdfd.hip"), os.path.join(ROOT, "tools", "asan", "loaders_asan.cpp"), "-o", exe], check=True)
+                    os.path.join(csrc, "bsdfd.hip"), os.path.join(csrc, "flow32.hip"), os.path.join(ROOT, "tools", "asan", "loaders_asan.cpp"), "-o", exe], check=True)
     raw = open(os.path.join(ROOT, "tests", "golden", "chm_orange_rgb.bsdf"), "rb").read()
     nf = struct.unpack_from("<I", raw, 14)[0]
     pos, rec = 18, {}
