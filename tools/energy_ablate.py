@@ -2,8 +2,9 @@
 """Where the ENERGY of the disk Euler step goes (the flow kernel is power-limited): ablated COPIES of csrc/flow32.hip
 (the product source is not touched) with one class of work removed — results are garbage, timing and clock are what is measured.
 
-    python tools/energy_ablate.py build     # -> build_ab/lib_abl_<name>.so   (needs build_ab/*.o of tools/ab_build32.sh)
-    python tools/energy_ablate.py run       # on the GPU box: kernel time, in-kernel clock, rocm-smi power per variant
+    python tools/energy_ablate.py build     # -> build_ab/lib_abl_<name>.so   (compiles build_ab/*.o through tools/ab_build32.sh if missing)
+    python tools/energy_ablate.py run       # on the GPU box: kernel time, in-kernel clock, socket power (hwmon of this GPU) per variant
+    python tools/energy_ablate.py           # both: the table of DESIGN.md §0 / profiles/r0N_ab/energy_ablate.jsonl in one command
 
 Variants: full | nomfma (every v_mfma_f32_32x32x16_f16 replaced by an opaque pass-through of its accumulator) | notrans (v_exp_f32 /
 v_rcp_f32 of the sigmoids replaced by one plain VALU op each) | nosplit (the hi/lo splits replaced by a plain fp16 pack: no v_and,
@@ -37,7 +38,7 @@ def patched(name):
             "template <bool WITH_G>\n__device__ __forceinline__ void act16(")
         rep("        if (WITH_G) silu_grad_scaled(z[v], hs[v], g[v]);", "        if (WITH_G) silu_grad_scaled_abl(z[v], hs[v], g[v]);")
     if "nosplit" in name:
-        rep("            split_pack<true>(x4, hi[c].p[2 * k], hi[c].p[2 * k + 1], lo[c].p[2 * k], lo[c].p[2 * k + 1]);",
+        rep("            split_pack<SPLIT>(x4, hi[c].p[2 * k], hi[c].p[2 * k + 1], lo[c].p[2 * k], lo[c].p[2 * k + 1]);",
             "            split_pack<false>(x4, hi[c].p[2 * k], hi[c].p[2 * k + 1], lo[c].p[2 * k], lo[c].p[2 * k + 1]);\n"
             "            lo[c].p[2 * k] = hi[c].p[2 * k]; lo[c].p[2 * k + 1] = hi[c].p[2 * k + 1];")
     return s
@@ -45,6 +46,8 @@ def patched(name):
 
 def build():
     os.makedirs(OUT, exist_ok=True)
+    if not all(os.path.exists(os.path.join(OUT, f"{t}.o")) for t in ("bsdfd", "wavefront", "encoding", "measured", "bucket", "clock")):
+        subprocess.run(["bash", os.path.join(ROOT, "tools", "ab_build32.sh"), "base", ""], check=True)
     common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed", "-I", os.path.join(ROOT, "include"), "-I", CS]
     procs = []
     for v in VARIANTS:
@@ -72,32 +75,22 @@ dev = torch.device("cuda")
 s = FlowSampler(W.load(W.shipped_path("aniso_miro_7_rgb", "disk")), tile=32)
 wi = bench.make_wi("disk", n, 1234, dev)
 wo = torch.empty((n, 3), device=dev); p = torch.empty(n, device=dev)
-pw = []
-stop = False
-def smi():
-    while not stop:
-        try:
-            r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
-            d = json.loads(r.stdout)["card0"]
-            pw.append((float(d["Current Socket Graphics Package Power (W)"]), d["sclk clock speed:"]))
-        except Exception:
-            pass
-        time.sleep(0.4)
+from bsdf_diffusion_sampling_amd.power import PowerSampler   # hwmon of THIS GPU (a node's sysfs shows all eight), rocm-smi as fallback
 t0 = time.time()
 while time.time() - t0 < 1.0:
     s.plugin_sample(wi, None, T=T, out=(wo, p)); torch.cuda.synchronize()
-th = threading.Thread(target=smi); th.start()
+ps = PowerSampler(); ps.start()
 s.set_profiling(True)
 t0 = time.time()
 while time.time() - t0 < 3.0:
     for _ in range(20): s.plugin_sample(wi, None, T=T, out=(wo, p))
     torch.cuda.synchronize()
 k, ms = s.profile_read(); mhz = s.profile_clock_mhz(); s.set_profiling(False)
-stop = True; th.join()
-watts = sorted(x for x, _ in pw)
+pw = ps.stop()
+w = pw["socket_power_w"]
 print(json.dumps({"variant": %(name)r, "us_per_launch": ms / k * 1e3, "in_kernel_mhz": mhz, "kcycles": ms / k * mhz,
-                  "socket_w_median": watts[len(watts) // 2] if watts else None, "sclk": pw[len(pw) // 2][1] if pw else None,
-                  "joule_per_launch": (watts[len(watts) // 2] * ms / k * 1e-3) if watts else None}))
+                  "socket_w_median": w, "sclk": pw["sclk_mhz"], "power_source": pw["source"], "power_samples": pw["samples"],
+                  "joule_per_launch": (w * ms / k * 1e-3) if w else None}))
 '''
 
 
@@ -111,4 +104,8 @@ def run():
 
 
 if __name__ == "__main__":
-    {"build": build, "run": run}[sys.argv[1]]()
+    if len(sys.argv) < 2:
+        build()
+        run()
+    else:
+        {"build": build, "run": run}[sys.argv[1]]()
