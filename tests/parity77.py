@@ -19,7 +19,8 @@ profiles/r06_plugin_parity_77sets.json): on the default tiling every set's upper
 pdf() at fresh directions, where the reference's own fp32 evaluation is 1.5e-3 and the kernel 5.6e-4 (EXEMPT, by name); on the
 16-query tiling one (set, call) sits AT the bound — cc_amber_citrine_rgb_disk pdf() at fresh directions, 1.05e-4 [1.02e-4,
 1.08e-4], reference fp32 3.1e-5 — listed in KNOWN_ABOVE_BOUND with a cap so that it can neither grow nor gain company unnoticed
-(neither the split-fp16 conditioning term nor round-to-nearest hi parts move it: profiles/r06_ab/).
+(neither the split-fp16 conditioning term nor round-to-nearest hi parts move it; the exact-fp32-MFMA kernels read 3.3e-5 there, the
+32-query split-fp16 kernels too: profiles/HISTORY.md, round 6 #15).
 
 This module is shared by tests/test_gpu_parity77.py (the assertion) and tools/plugin_parity_sweep.py (the committed record,
 profiles/r06_plugin_parity_77sets.json).  The oracle half runs in worker PROCESSES that import numpy + oracle only.
@@ -82,7 +83,7 @@ def make_inputs(stem, dom, full, n):
     return {"wi3": wi3, "x0": x0.astype(np.float32), "wl3": wl3}
 
 
-def gpu_eval(stem, dom, full, inp, tiles=(32, 16)):
+def gpu_eval(stem, dom, full, inp, tiles=(32, 16), precision="split3"):
     """The HIP path through the C ABI (FlowSampler, ctypes/torch binding as configured), per tiling:
     {tile: {"wo": [n,3], "sample": pdf_sa, "pdf_a": ..., "pdf_b": ...}} + "wo_a" = the fp32 directions pdf_a is asked at
     (the first tiling's samples)."""
@@ -96,8 +97,8 @@ def gpu_eval(stem, dom, full, inp, tiles=(32, 16)):
     wi, x0, wl = t(inp["wi3"]), t(inp["x0"]), t(inp["wl3"])
     out, wo_a = {}, None
     for tile in tiles:
-        s = FlowSampler(fw, precision="split3", tile=tile)
-        assert s.tile == tile, (stem, tile, s.tile)
+        s = FlowSampler(fw, precision=precision, tile=tile if precision == "split3" else 0)
+        assert s.tile == tile or precision != "split3", (stem, tile, s.tile)
         wo, pdf = s.plugin_sample(wi, x0, T=T, variant=variant)
         if wo_a is None:
             wo_a = wo.clone()
@@ -242,7 +243,7 @@ def verdict(row, tiles=(32, 16), stem=None):
     return fails, exempt, known
 
 
-def run(n=65536, sets=None, tiles=(32, 16), workers=None, log=print):
+def run(n=65536, sets=None, tiles=(32, 16), workers=None, log=print, precision="split3"):
     """The whole sweep: GPU evaluation in this process, the oracle in ``workers`` spawned processes.  -> {"summary", "sets"}."""
     import multiprocessing as mp
     import time
@@ -257,7 +258,7 @@ def run(n=65536, sets=None, tiles=(32, 16), workers=None, log=print):
     with ctx.Pool(workers) as pool:
         for stem, dom, full in sets:
             inp = make_inputs(stem, dom, full, n)
-            g = gpu_eval(stem, dom, full, inp, tiles)
+            g = gpu_eval(stem, dom, full, inp, tiles, precision)
             pending[stem] = (dom, full, g, pool.apply_async(oracle_eval, ((stem, dom, full, inp, g["wo_a"]),)))
         log(f"parity77: GPU half of {len(sets)} sets done in {time.time() - t0:.0f} s; waiting for the oracle ({workers} workers)")
         for stem, (dom, full, g, fut) in pending.items():

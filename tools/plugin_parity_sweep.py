@@ -21,11 +21,14 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "plugin_parity_77sets.json"))
     ap.add_argument("--only", default=None, help="substring filter on the set names")
     ap.add_argument("--tiles", default="32,16")
+    ap.add_argument("--precision", default="split3", help="split3 (the product) | f32: the exact-fp32-MFMA validation kernels (16-query tiles "
+                                                          "only: pass --tiles 16; the tile label then names the row, not the kernel)")
     a = ap.parse_args()
     import parity77 as P
     from bsdf_diffusion_sampling_amd import _lib
     sets = [s for s in P.all_sets() if a.only is None or a.only in s[0]]
-    rec = P.run(n=a.n, sets=sets, tiles=tuple(int(t) for t in a.tiles.split(",")))
+    rec = P.run(n=a.n, sets=sets, tiles=tuple(int(t) for t in a.tiles.split(",")), precision=a.precision)
+    rec["summary"]["precision"] = a.precision
     rec["summary"]["library"] = _lib.lib().bsdfd_version().decode()
     rec["summary"]["kernel_source_sha256"] = _lib.kernel_source_sha256()
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
