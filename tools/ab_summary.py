@@ -33,7 +33,7 @@ for t in tags:
 # energy next to time (the kernels are power-limited: what an optimisation buys is what it saves in joules per query)
 ew = [w for w in dict.fromkeys(w for w, _ in keys) if any(w in r and "joule_per_Mquery" in r[w] for r in rows)]
 if ew:
-    print("%-14s" % "J/Mquery | W | in-kernel MHz" + "".join("%26s" % w for w in ew))
+    print("%-14s" % "J/Mquery (ratio) | W | in-kernel MHz | Mcycles per sample launch" + "".join("%34s" % w for w in ew))
     for t in tags:
         line = "%-14s" % t
         for w in ew:
@@ -43,7 +43,9 @@ if ew:
                 j0 = [x[w]["joule_per_Mquery"] for x in rows if x["tag"] == tags[0] and w in x and x[w].get("joule_per_Mquery")]
                 watts = float(np.median([x["watts"] for x in rr]))
                 mhz = [x.get("sample_mhz") or x.get("mhz") for x in rr if (x.get("sample_mhz") or x.get("mhz"))]
-                line += "%9.4f(%5.3f)%5.0fW%5.0f" % (j, j / float(np.median(j0)) if j0 else float("nan"), watts, float(np.median(mhz)) if mhz else 0)
+                cyc = [x.get("sample_Mcycles") or (x.get("ms", 0) * (x.get("mhz") or 0) * 1e-3) for x in rr]
+                line += "%9.4f(%5.3f)%5.0fW%5.0f%8.3f" % (j, j / float(np.median(j0)) if j0 else float("nan"), watts,
+                                                         float(np.median(mhz)) if mhz else 0, float(np.median(cyc)) if cyc else 0)
             else:
-                line += "%26s" % "-"
+                line += "%34s" % "-"
         print(line)
