@@ -175,7 +175,14 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
 
     Either failing aborts the build: the library could compute with stale registers.  ``BSDFD_ALLOW_UNVERIFIED_BUILD=1`` ships it
     anyway, loudly — ``<lib>.build.json`` ("unverified": true), ``<lib>.asmcheck.txt`` (every finding) and ``bsdfd_version()``
-    ("UNVERIFIED BUILD") record it.  ``<lib>.build.json`` and ``bsdfd_version()`` also say which LDS variant shipped."""
+    ("UNVERIFIED BUILD") record it.  ``<lib>.build.json`` and ``bsdfd_version()`` also say which LDS variant shipped.
+
+    ``BSDFD_COMPILER_ONLY_BUILD=1`` — for a toolchain whose assembly the parser does not understand: both
+    flow-kernel translation units are compiled with ``-DBSDFD_NO_ASYNC_LDS -DBSDFD_NO_SDWA_PACK``, i.e. WITHOUT the two constructs
+    whose safety rests on the assembly checks (the inline-asm LDS reads; the packed-fp16 sigmoids' SDWA blocks): every LDS read and
+    every fp16 sigmoid is then ordinary compiler-scheduled code, a few per cent slower, same results.  The assembly is not parsed at
+    all (only searched, as text, for the two constructs); the hand-padded wait states behind the MFMAs the compiler was caught
+    omitting stay in the source.  Recorded in ``<lib>.build.json`` ("compiler_only": true) and in ``bsdfd_version()``."""
     import json
     import tempfile
     out = lib_path or LIB_PATH
@@ -188,8 +195,10 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
     # launch, a parallel test worker) never dlopens a half-written library
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     tmp = f"{out}.tmp.{os.getpid()}"
-    info = {"variant": "async", "violations": {}, "hipcc": None, "unverified": False}
+    info = {"variant": "async", "violations": {}, "hipcc": None, "unverified": False, "compiler_only": False}
     allow_unverified = os.environ.get("BSDFD_ALLOW_UNVERIFIED_BUILD") == "1"
+    compiler_only = os.environ.get("BSDFD_COMPILER_ONLY_BUILD") == "1"
+    CO_FLAGS = ["-DBSDFD_NO_ASYNC_LDS", "-DBSDFD_NO_SDWA_PACK", "-DBSDFD_COMPILER_ONLY_BUILD"]
     try:
         v = subprocess.run(["hipcc", "--version"], capture_output=True, text=True)
         info["hipcc"] = next((l.strip() for l in v.stdout.splitlines() if "version" in l.lower()), None)
@@ -200,7 +209,8 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
         for src in SRC_PATHS[1:]:   # the other translation units in parallel with csrc/bsdfd.hip (the long one)
             obj = os.path.join(td, os.path.basename(src)[:-4] + ".o")
             side.append(obj)
-            cmd = _flow_tu_cmd(td, src, []) if src in FLOW_TUS else ["hipcc", *HIPCC_FLAGS, "-I", INCLUDE_DIR, "-c", src, "-o", obj]
+            cmd = (_flow_tu_cmd(td, src, CO_FLAGS if compiler_only else []) if src in FLOW_TUS
+                   else ["hipcc", *HIPCC_FLAGS, "-I", INCLUDE_DIR, "-c", src, "-o", obj])
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd, cwd=td)))
@@ -218,9 +228,13 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
 
         findings = []
         try:
-            asm = _compile_flow_tu(td, [], verbose)
-            bad = _check_asm(asm)
-            blind = _census([asm], "async", only="flow_kernelI")
+            asm = _compile_flow_tu(td, CO_FLAGS if compiler_only else [], verbose)
+            bad = {} if compiler_only else _check_asm(asm)
+            blind = [] if compiler_only else _census([asm], "async", only="flow_kernelI")
+            if compiler_only:
+                info["variant"], info["compiler_only"] = "plain", True
+                print("=" * 100 + "\nbsdfd build: BSDFD_COMPILER_ONLY_BUILD=1 — no inline-asm LDS reads, no SDWA sigmoids; the device assembly is NOT "
+                      "inspected (bsdfd_version() says so)\n" + "=" * 100, flush=True)
             if bad or blind:
                 info["variant"] = "plain"
                 info["violations"] = {k: v[:8] for k, v in bad.items()} or {"census": blind[:8]}
@@ -243,10 +257,20 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
         if failed:
             raise subprocess.CalledProcessError(*failed)
         asms = [asm] + [_flow_tu_asm(td, src) for src in FLOW_TUS[1:]]
-        fatal = [f"census: {m}" for m in _census(asms, info["variant"])]
-        for a in asms:
-            for k, msgs in _check_asm_mfma(a).items():
-                fatal += [f"{os.path.basename(a)}: {k}: {m}" for m in msgs]
+        fatal = []
+        if compiler_only:
+            # a TEXT search, independent of the parser: neither of the two constructs may be left in the code
+            text = "".join(open(a).read() for a in asms)
+            blocks = [blk.split("#ASMEND")[0] for blk in text.split("#ASMSTART")[1:]]   # (the compiler's own SDWA forms are its business)
+            info["inline_asm_constructs_left"] = {"ds_read_b128 inside inline asm": sum(1 for blk in blocks if "ds_read_b128" in blk),
+                                                  "_sdwa inside inline asm": sum(1 for blk in blocks if "_sdwa" in blk)}
+            if any(info["inline_asm_constructs_left"].values()):
+                raise RuntimeError(f"compiler-only build still contains inline-asm constructs: {info['inline_asm_constructs_left']}")
+        else:
+            fatal = [f"census: {m}" for m in _census(asms, info["variant"])]
+            for a in asms:
+                for k, msgs in _check_asm_mfma(a).items():
+                    fatal += [f"{os.path.basename(a)}: {k}: {m}" for m in msgs]
         findings += fatal
         if findings:
             with open(out + ".asmcheck.txt", "w") as f:
@@ -276,7 +300,7 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
                 json.dump(info, f, indent=1)
             os.replace(f"{out}.build.json.tmp.{os.getpid()}", out + ".build.json")
             os.replace(tmp, out)
-            if os.path.abspath(out) == DEFAULT_LIB_PATH and not fatal:
+            if os.path.abspath(out) == DEFAULT_LIB_PATH and not fatal and not compiler_only:
                 # the verified assembly of the library that is NOW in place, kept for tools/isa_mix.py and the census tests (build/ is
                 # scratch; a read-only tree must not fail the build).  Only for the default product path — never for an A/B library
                 # selected with $BSDFD_LIB_PATH — and stamped with the kernel sources' hash, which the readers compare.
@@ -295,7 +319,7 @@ def build(force: bool = False, verbose: bool = False, lib_path: str = None) -> s
                     os.remove(leftover)
     if verbose:
         print(f"bsdfd build: shipped the {'asynchronous-LDS' if info['variant'] == 'async' else 'FALLBACK (compiler-managed LDS)'} "
-              f"variant of the flow kernels ({out})", flush=True)
+              f"variant of the flow kernels{' — COMPILER-ONLY build' if compiler_only else ''} ({out})", flush=True)
     return out
 
 

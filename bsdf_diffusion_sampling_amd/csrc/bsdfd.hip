@@ -2040,12 +2040,14 @@ float bsdfd_last_kernel_ms(bsdfd_handle h) {
 }
 
 const char* bsdfd_last_error(void) { return g_err.c_str(); }
-#ifdef BSDFD_UNVERIFIED_BUILD
+#if defined(BSDFD_COMPILER_ONLY_BUILD)
+#define BSDFD_VERIFIED_TAG "; COMPILER-ONLY BUILD (BSDFD_COMPILER_ONLY_BUILD=1): no inline-asm LDS reads or SDWA sigmoids, device assembly not inspected"
+#elif defined(BSDFD_UNVERIFIED_BUILD)
 #define BSDFD_VERIFIED_TAG "; UNVERIFIED BUILD: shipped with BSDFD_ALLOW_UNVERIFIED_BUILD=1 although the assembly checks failed"
 #else
 #define BSDFD_VERIFIED_TAG ""
 #endif
-const char* bsdfd_version(void) { return "bsdfd 0.6 (gfx950; " BSDFD_LDS_VARIANT BSDFD_VERIFIED_TAG ")"; }
+const char* bsdfd_version(void) { return "bsdfd 0.6 (gfx950; " BSDFD_LDS_VARIANT BSDFD_SIGMOID_VARIANT BSDFD_VERIFIED_TAG ")"; }
 int32_t bsdfd_abi_version(void) { return BSDFD_ABI_VERSION; }
 
 }  // extern "C"

@@ -236,6 +236,8 @@ __device__ __forceinline__ void split_pack(const float (&x)[4], f16x2& h01, f16x
 // v_cvt_f16_f32 + v_pack_b32_f16, ~1.3x the VALU).  Every result is written >= 3 instructions before it is touched again and one
 // wait state separates the block from its consumers: a VALU reading a transcendental's or a dst_sel write's result needs one on
 // gfx940-class parts, and the compiler's hazard recogniser does not look inside an asm statement.
+#ifndef BSDFD_NO_SDWA_PACK
+#define BSDFD_SIGMOID_VARIANT ""
 #define BSDFD_PK4_TRANS(OP, R, X)                                                                                             \
     asm(OP "_e32 %0, %4\n\t" OP "_e32 %1, %5\n\t" OP "_e32 %2, %6\n\t" OP "_e32 %3, %7\n\t"                                \
         OP "_sdwa %0, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"                                       \
@@ -258,6 +260,21 @@ __device__ __forceinline__ void act_pack8(const float (&zs)[8], Frag& b) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) b.p[k] = zh[k] * sg[k];
 }
+#else
+// -DBSDFD_NO_SDWA_PACK (the compiler-only build, BSDFD_COMPILER_ONLY_BUILD=1 in _lib.build()): the same arithmetic — pre-activation
+// rounded to fp16, v_exp_f16, add, v_rcp_f16, multiply — written value by value for the compiler, which converts and re-packs each
+// value itself (~1.3x the VALU of the hand-packed form, +4 % teacher time when measured in round 5) and pads its own hazards.
+#define BSDFD_SIGMOID_VARIANT "; compiler-written fp16 sigmoids"
+__device__ __forceinline__ void act_pack8(const float (&zs)[8], Frag& b) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const _Float16 z0 = (_Float16)zs[2 * k], z1 = (_Float16)zs[2 * k + 1];
+        const _Float16 s0 = __builtin_amdgcn_rcph((_Float16)1.0f + __builtin_elementwise_exp2(z0));
+        const _Float16 s1 = __builtin_amdgcn_rcph((_Float16)1.0f + __builtin_elementwise_exp2(z1));
+        b.p[k] = (f16x2){z0 * s0, z1 * s1};
+    }
+}
+#endif
 __device__ __forceinline__ float sel4(int g, float a0, float a1, float a2, float a3) {
     return g == 0 ? a0 : (g == 1 ? a1 : (g == 2 ? a2 : a3));
 }

@@ -38,6 +38,14 @@ for stem in ("aniso_miro_7_rgb_disk", "aniso_miro_7_rgb_spherical", "aniso_miro_
     out[stem] = {{"x_err": float(np.abs(x.cpu().numpy() - xo).max()), "p99": float(np.percentile(rel, 99)),
                  "x": x.cpu().numpy().tobytes().hex()[:4096], "sum_p": float(p.double().sum()), "sum_pp": float(pp.double().sum())}}
     s.close()
+# the f16 samples-only call (packed-fp16 sigmoids: hand-packed SDWA form in the product, compiler-written in the compiler-only build)
+g, fw = load_case("aniso_miro_7_rgb_spherical_complex")
+for tile in (32, 16):
+    s = FlowSampler(fw, precision="f16", tile=tile)
+    xs = s.flow_samples_only(t(g["wi"]), t(g["x0"]), T=32)
+    out["teacher_f16_tile%d" % tile] = {{"x": xs.cpu().numpy().tobytes().hex()[:4096], "sum": float(xs.double().sum()),
+                                        "finite": bool(torch.isfinite(xs).all())}}
+    s.close()
 print("RESULT" + json.dumps(out))
 """
 
@@ -72,3 +80,24 @@ def test_fallback_build_is_correct_and_agrees_with_the_product_build(tmp_path, m
         assert fb[stem]["x_err"] < 1e-4 and fb[stem]["p99"] < 1e-4, (stem, fb[stem])
         # the same arithmetic in the same order: only WHEN the fragments are fetched differs
         assert fb[stem]["x"] == prod[stem]["x"] and fb[stem]["sum_p"] == prod[stem]["sum_p"] and fb[stem]["sum_pp"] == prod[stem]["sum_pp"], stem
+
+
+def test_compiler_only_build_is_correct_and_agrees_with_the_product_build(tmp_path, monkeypatch):
+    """BSDFD_COMPILER_ONLY_BUILD=1 (no inline-asm LDS reads, no SDWA sigmoids, nothing parsed — the build for a toolchain the
+    assembly parser does not know): the same arithmetic in the same order everywhere, so every result equals the product build's bit
+    for bit — the split3 operators AND the f16 samples-only call whose sigmoids the compiler now writes."""
+    if not shutil.which("hipcc"):
+        pytest.skip("needs hipcc")
+    from bsdf_diffusion_sampling_amd import _lib
+    monkeypatch.setenv("BSDFD_COMPILER_ONLY_BUILD", "1")
+    out = str(tmp_path / "libbsdfd_compiler_only.so")
+    _lib.build(force=True, lib_path=out)
+    monkeypatch.delenv("BSDFD_COMPILER_ONLY_BUILD")
+    assert _lib.build_info(out)["compiler_only"] is True
+    co, prod = _run(out), _run(None)
+    assert "COMPILER-ONLY BUILD" in co["version"] and "COMPILER-ONLY" not in prod["version"]
+    for stem in ("aniso_miro_7_rgb_disk", "aniso_miro_7_rgb_spherical", "aniso_miro_7_rgb_spherical_complex"):
+        assert co[stem]["x_err"] < 1e-4 and co[stem]["p99"] < 1e-4, (stem, co[stem])
+        assert co[stem]["x"] == prod[stem]["x"] and co[stem]["sum_p"] == prod[stem]["sum_p"] and co[stem]["sum_pp"] == prod[stem]["sum_pp"], stem
+    for key in ("teacher_f16_tile32", "teacher_f16_tile16"):
+        assert co[key]["finite"] and co[key]["x"] == prod[key]["x"] and co[key]["sum"] == prod[key]["sum"], key

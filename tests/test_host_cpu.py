@@ -662,6 +662,38 @@ def test_build_refuses_an_unverifiable_compilation_unless_overridden(tmp_path, m
     assert _lib.build_info().get("unverified") is False and b"UNVERIFIED" not in _lib.lib().bsdfd_version()
 
 
+def test_compiler_only_build(tmp_path, monkeypatch, capsys):
+    """BSDFD_COMPILER_ONLY_BUILD=1 ("a ROCm bump will stop every build until someone updates the parser; there is
+    no compiler-only fallback for act_pack8"): both flow translation units are compiled without the inline-asm LDS reads and without
+    the SDWA sigmoids, nothing is parsed — the checkers are never called — and the library says what it is."""
+    import ctypes as C
+    import shutil
+    if not shutil.which("hipcc"):
+        pytest.skip("needs hipcc")
+    from bsdf_diffusion_sampling_amd import _lib
+
+    def never(*a, **k):
+        raise AssertionError("the compiler-only build must not call the assembly checkers")
+    for seam in ("_check_asm", "_check_asm_mfma", "_census"):
+        monkeypatch.setattr(_lib, seam, never)
+    monkeypatch.setenv("BSDFD_COMPILER_ONLY_BUILD", "1")
+    out = str(tmp_path / "libbsdfd_compiler_only.so")
+    assert _lib.build(force=True, lib_path=out) == out
+    info = _lib.build_info(out)
+    assert info["compiler_only"] is True and info["variant"] == "plain" and info["unverified"] is False
+    assert info["inline_asm_constructs_left"] == {"ds_read_b128 inside inline asm": 0, "_sdwa inside inline asm": 0}
+    assert "BSDFD_COMPILER_ONLY_BUILD=1" in capsys.readouterr().out
+    import torch  # noqa: F401  (the HIP runtime the library links against)
+    L = C.CDLL(out)
+    L.bsdfd_version.restype = C.c_char_p
+    v = L.bsdfd_version()
+    assert b"COMPILER-ONLY BUILD" in v and b"compiler-written fp16 sigmoids" in v and b"fallback" in v
+    for name in _lib.EXPORTS:
+        getattr(L, name)
+    # the product library of this tree is untouched by it
+    assert _lib.build_info().get("compiler_only") in (False, None) and b"COMPILER-ONLY" not in _lib.lib().bsdfd_version()
+
+
 def test_build_falls_back_to_compiler_managed_lds_reads_when_the_asm_check_fails(tmp_path, monkeypatch, capsys):
     """_lib.build() verifies the assembly of ITS OWN compilation of csrc/bsdfd.hip and, when an instruction touches the
     destination of an asynchronous LDS read before its wait, rebuilds with -DBSDFD_NO_ASYNC_LDS instead of shipping a library
