@@ -69,7 +69,7 @@ def test_bench_line_single_gpu_with_secondary_and_cpu_baseline():
     # energy is a first-class figure (the kernels are power-limited): socket power polled while the workload's own
     # passes run back to back, joules per million sample()+pdf() queries — for the judged workload and every secondary one
     board = d["roofline"]["board"]
-    assert "error" not in board and board["source"] is not None and board["samples"] >= 2, board
+    assert "error" not in board and board["source"] is not None and board["samples"] >= 1, board
     assert 200 < board["socket_power_w"] < 1600 and 200 < d["roofline"]["socket_power_w"] < 1600, board
     assert d["roofline"]["joule_per_Mquery"] == board["joule_per_Mquery"]
     # consistency: J/Mquery x Mquery/s = W
