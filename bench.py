@@ -987,16 +987,16 @@ def worker(a):
                 roof["issue_bound"] = ib
             except Exception as exc:
                 roof["issue_bound"] = {"error": repr(exc)}
-            # the board's own view while the judged kernel runs back to back (outside the timed region): the flow kernel is
-            # power-limited — socket power at the limit, shader clock below boost
-            if rank == 0 and world == 1:
-                try:
-                    roof["board"] = board_energy(wl)
-                    roof["flow_launches_after_timed_region"] += roof["board"].pop("launches", 0)
-                except Exception as exc:
-                    roof["board"] = {"error": repr(exc)}
-                roof["joule_per_Mquery"] = roof["board"].get("joule_per_Mquery")
-                roof["socket_power_w"] = roof["board"].get("socket_power_w")
+        # the board's own view while the judged workload's passes run back to back (outside the timed region, whatever the
+        # workload): the flow kernels are power-limited — socket power at the limit, shader clock below boost
+        if rank == 0 and world == 1:
+            try:
+                roof["board"] = board_energy(wl)
+                roof["flow_launches_after_timed_region"] = roof.get("flow_launches_after_timed_region", 0) + roof["board"].pop("launches", 0)
+            except Exception as exc:
+                roof["board"] = {"error": repr(exc)}
+            roof["joule_per_Mquery"] = roof["board"].get("joule_per_Mquery")
+            roof["socket_power_w"] = roof["board"].get("socket_power_w")
         out["roofline"] = roof
         if world == 1 and not a.no_secondary:
             sec = {}
