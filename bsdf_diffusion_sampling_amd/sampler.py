@@ -45,9 +45,10 @@ class FlowSampler:
                  binding: Optional[str] = None, tile: int = 0):
         """``binding``: 'ctypes' or 'torch' — which host shim the per-call entry points go through (default:
         ``default_binding()``).  The handle is created through the C ABI either way and is the same object.
-        ``tile``: bsdfd_desc.tile — 0 (default), 16 or 32 queries per wave tile.  With 0, ``$BSDFD_TILE=16`` selects the 16-query
-        kernels (A/B runs of one build; the LIBRARY reads no environment variable — this host maps it onto the field; "32" is the
-        default anyway wherever such a kernel exists).  An explicit 32 for a net / precision without a 32-query kernel raises."""
+        ``tile``: bsdfd_desc.tile — 0 (default), 16 or 32 queries per wave tile.  With 0, ``$BSDFD_TILE=16`` / ``=32`` select the
+        16- / 32-query kernels (A/B runs of one build; the LIBRARY reads no environment variable — this host maps it onto the
+        field; 32 also selects the opt-in 32-query kernel of the 64 x 6 net and falls back to the default where none exists).
+        An explicit ``tile=32`` ARGUMENT for a net / precision without a 32-query kernel raises."""
         if not torch.cuda.is_available():
             raise RuntimeError("FlowSampler needs an MI355X (torch.cuda is unavailable); there is no CPU path")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
@@ -61,10 +62,11 @@ class FlowSampler:
         d.base_hidden, d.base_pe_bands = fw.base_hidden, fw.base_pe_bands
         d.precision = _lib.PRECISIONS[precision] if isinstance(precision, str) else int(precision)
         d.tile = int(tile)
+        env_tile = 0
         if d.tile == 0:
             import os
-            if os.environ.get("BSDFD_TILE", "").strip() == "16":
-                d.tile = 16
+            env_tile = {"16": 16, "32": 32}.get(os.environ.get("BSDFD_TILE", "").strip(), 0)
+            d.tile = env_tile   # (32 from the ENVIRONMENT is a preference: also selects the opt-in 32-query kernels, falls back below)
         keep = []
         for name in ("w_in", "w_hidden", "w_out", "base_w1", "base_b1", "base_w2", "base_b2"):
             a = np.ascontiguousarray(getattr(fw, name), dtype=np.float32)
@@ -72,7 +74,11 @@ class FlowSampler:
             setattr(d, name, a.ctypes.data_as(C.POINTER(C.c_float)))
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(L.bsdfd_create(C.byref(d), C.byref(h)))
+            rc = L.bsdfd_create(C.byref(d), C.byref(h))
+            if rc != 0 and env_tile == 32 and int(tile) == 0 and b"tile = 32" in L.bsdfd_last_error():
+                d.tile = 0   # this net / precision has no 32-query kernel: $BSDFD_TILE=32 then means the library's default
+                rc = L.bsdfd_create(C.byref(d), C.byref(h))
+            _lib.check(rc)
         self._h = h
         self._L = L
         self.binding = binding or default_binding()
