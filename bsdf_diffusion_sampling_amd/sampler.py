@@ -8,6 +8,7 @@ only native binding (tiny-cuda-nn/bindings/torch/tinycudann/bindings.cpp:54-73).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -291,6 +292,13 @@ class FlowSampler:
         self._chk_index(row_index, None, "row_index")
         if row_index is not None and row_index.shape[0] > m:
             raise RuntimeError(f"row_index names {row_index.shape[0]} rows, the arrays have {m}")
+        if row_index is not None and row_index.numel() and os.environ.get("BSDFD_CHECK_INDEX", "0") not in ("", "0"):
+            # debugging aid (one device->host sync per call): the library cannot check this, it does not know the arrays' lengths
+            lo, hi = int(row_index.min()), int(row_index.max())
+            if lo < 0 or hi >= m:
+                raise RuntimeError(f"row_index entries span [{lo}, {hi}], the arrays have rows [0, {m})")
+            if int(torch.unique(row_index).numel()) != row_index.numel():
+                raise RuntimeError("row_index names a row more than once")
         return m if row_index is None else row_index.shape[0]
 
     def _plugin_sample_ex(self, wi, x0, T, variant, seed, offset, out, ctx, rng_index, ctx_read=False, row_index=None):

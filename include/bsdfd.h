@@ -198,7 +198,9 @@ typedef struct bsdfd_opts {
                                 * material called on its lanes, rendering/matpreview/disney_bsdf_array0_envmap.xml +
                                 * rendering/brdf_measured_disk.py:140).  seg_end, the per-query context and rng_index stay
                                 * indexed by i; without rng_index the Philox counter of row i is offset + row_index[i].
-                                * Rows not named by row_index are not touched.  Entries must be distinct.               */
+                                * Rows not named by row_index are not touched.  Entries must be distinct and inside the
+                                * callers' arrays; the library cannot check either (it is not told the arrays' lengths;
+                                * the Python hosts do under BSDFD_CHECK_INDEX=1).                                      */
 } bsdfd_opts;
 int bsdfd_plugin_sample_ex(bsdfd_handle h, int32_t variant, const float* wi, const float* x0, uint64_t seed,
                            uint64_t offset, int64_t N, int32_t T, float* wo, float* pdf_sa, const bsdfd_opts* opts,

@@ -68,7 +68,7 @@ def test_single_material_calls_through_a_row_index(stem, variant, tile, binding)
     s.close()
 
 
-def test_row_index_argument_checks():
+def test_row_index_argument_checks(monkeypatch):
     from bsdf_diffusion_sampling_amd.sampler import FlowSampler
     _, fw = load_case("chm_orange_rgb_disk")
     wi = _dirs(64, 5)
@@ -80,6 +80,14 @@ def test_row_index_argument_checks():
             s.plugin_sample(wi, None, row_index=torch.arange(65, device=_dev()))                         # more rows than the arrays
         with pytest.raises(RuntimeError):
             s.plugin_pdf(wi, wi, row_index=torch.arange(64))                                             # host tensor
+        # what the library cannot see (it is not told the arrays' lengths) the hosts check on request
+        monkeypatch.setenv("BSDFD_CHECK_INDEX", "1")
+        with pytest.raises(RuntimeError, match="span"):
+            s.plugin_sample(wi, None, row_index=torch.tensor([0, 64], device=_dev()))
+        with pytest.raises(RuntimeError, match="more than once"):
+            s.plugin_pdf(wi, wi, row_index=torch.tensor([3, 3], device=_dev()))
+        s.plugin_sample(wi, None, row_index=torch.tensor([5, 63, 0], device=_dev()))
+        monkeypatch.delenv("BSDFD_CHECK_INDEX")
         s.close()
 
 
