@@ -60,6 +60,12 @@ def test_single_material_calls_through_a_row_index(stem, variant, tile, binding)
     wo3, pdf3 = s.plugin_sample(wi, None, T=T, variant=variant, seed=9, offset=100, row_index=rows, ctx_out=ctx)
     assert torch.equal(wo3[rows], wo_g) and torch.equal(pdf3[rows], pdf_g)
     assert torch.equal(s.plugin_pdf(wi, wl, T=T, variant=variant, row_index=rows, ctx_in=ctx)[rows], p_g)
+    # an index that names no row: nothing runs, nothing is written
+    none = torch.empty(0, dtype=torch.int64, device=_dev())
+    wo0, pdf0 = torch.full((m, 3), -7.0, device=_dev()), torch.full((m,), -7.0, device=_dev())
+    s.plugin_sample(wi, None, T=T, variant=variant, out=(wo0, pdf0), row_index=none)
+    s.plugin_pdf(wi, wl, T=T, variant=variant, out=pdf0, row_index=none)
+    assert (wo0 == -7.0).all() and (pdf0 == -7.0).all()
     # the identity index is the plain call
     ident = torch.arange(m, device=_dev())
     a = s.plugin_sample(wi, None, T=T, variant=variant, seed=1, row_index=ident)
