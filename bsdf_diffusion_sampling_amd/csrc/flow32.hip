@@ -66,6 +66,12 @@ constexpr int FR32 = 64 * 16;  // bytes of one A fragment (32 rows x 16 K-values
 #endif                               // instead of 11 exact-fp32 v_mfma_f32_32x32x2_f32.  Round 6, NEGATIVE: -0.5 % kernel time (T = 8) for 6-10 % of
                                      // the accuracy margin (worst of the 50 spherical-domain sets at 65 536 queries: sample 5.9e-5 -> 6.5e-5, pdf at
                                      // produced directions 6.7e-5 -> 7.2e-5, at fresh ones 8.6e-5 -> 9.1e-5 [9.8e-5]; profiles/r06_ab/ab32_spherical_*)
+#ifndef BSDFD_T32_L1_RN
+#define BSDFD_T32_L1_RN 1             // the hi parts of layer 1's STATE operands (x / theta, sin phi, cos phi, alpha) are ROUNDED to fp16, not
+#endif                                // truncated: hi + lo then carries 23 bits instead of 22 for one v_cvt_f32_f16 in place of a v_and.  The state
+                                      // operands' quantisation was the largest single term of the worst (set, call) of the 77-set sweep (CPU:
+                                      // tools/archive/r06_state_split_diag.py, bsdf_24 pdf() at fresh directions 5.2e-5 -> 3.2e-5 of its 8.6e-5);
+                                      // measured: 8.6e-5 [9.2e-5] -> 7.6e-5 [8.3e-5], time and J/query 0.999-1.002 (profiles/r06_ab/ab32_l1_rn.txt)
 #ifndef BSDFD_T32_SPH_FOLD_T0
 #define BSDFD_T32_SPH_FOLD_T0 1      // spherical d/dtheta tangent through a folded matrix: the layer-1 tangent is g1 . W1[:, theta] with a CONSTANT
 #endif                               // column, so W2 (g1 . W1[:, theta]) = F_theta g1, F_theta = W2 diag(W1[:, theta]) packed by the host (the disk
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(256, (FUSED && DOMAIN == BSDFD_DOMAIN_SPHERICAL) ? 
                 vin = h ? sp : xs;
                 win = h ? cp : alpha;
             }
-            const float vh = BSDFD_SPLIT_RN ? hi_part_rn(vin) : hi_part(vin), wh = BSDFD_SPLIT_RN ? hi_part_rn(win) : hi_part(win);
+            const float vh = (BSDFD_SPLIT_RN || BSDFD_T32_L1_RN) ? hi_part_rn(vin) : hi_part(vin), wh = (BSDFD_SPLIT_RN || BSDFD_T32_L1_RN) ? hi_part_rn(win) : hi_part(win);
             const f16x2 zero2 = {(_Float16)0.0f, (_Float16)0.0f};
             const f16x2 vp = {(_Float16)vh, (_Float16)(vin - vh)}, wp = {(_Float16)wh, (_Float16)(win - wh)};
             Frag b1;

@@ -16,11 +16,11 @@ Rows counted: ``det`` — the contract's error metric: densit
 and |prod det J| in [1e-3, 1e3]; ``all`` — every resolved row (what tests/test_gpu_parity.py's plugin-level fixtures count).
 p99 carries a percentile-bootstrap 95 % interval (B resamples of the rows).  What round 6 measured with it (N = 65 536,
 profiles/r06_plugin_parity_77sets.json): on the default tiling every set's upper interval end is below 1e-4 except bsdf_23's
-pdf() at fresh directions, where the reference's own fp32 evaluation is 1.5e-3 and the kernel 5.6e-4 (EXEMPT, by name); on the
-16-query tiling one (set, call) sits AT the bound — cc_amber_citrine_rgb_disk pdf() at fresh directions, 1.05e-4 [1.02e-4,
-1.08e-4], reference fp32 3.1e-5 — listed in KNOWN_ABOVE_BOUND with a cap so that it can neither grow nor gain company unnoticed
-(neither the split-fp16 conditioning term nor round-to-nearest hi parts move it; the exact-fp32-MFMA kernels read 3.3e-5 there, the
-32-query split-fp16 kernels too: profiles/HISTORY.md, round 6 #15).
+pdf() at fresh directions, where the reference's own fp32 evaluation is 1.5e-3 and the kernel 5.6e-4 (EXEMPT, by name).  The
+16-query tiling held one (set, call) AT the bound — cc_amber_citrine_rgb_disk pdf() at fresh directions, 1.05e-4 [1.02e-4, 1.08e-4],
+reference fp32 3.1e-5 — until its cause was found (profiles/HISTORY.md, round 6 #19: the output layer's W_lo rows were fp16
+subnormals, a fixed perturbation of the weights that move the state) and removed (csrc/bsdfd.hip, BSDFD_WO_LO_SCALE): 4.9e-5;
+KNOWN_ABOVE_BOUND is empty.
 
 This module is shared by tests/test_gpu_parity77.py (the assertion) and tools/plugin_parity_sweep.py (the committed record,
 profiles/r06_plugin_parity_77sets.json).  The oracle half runs in worker PROCESSES that import numpy + oracle only.
@@ -153,7 +153,7 @@ def _p99_ci(e, rng, boot=BOOT):
     return p99, float(np.percentile(b, 2.5)), float(np.percentile(b, 97.5))
 
 
-def stats(got, want, want32, acc, seed=0):
+def stats(got, want, want32, acc, seed=0, exclude=None):
     """Error figures of one (set, kind, tiling).  Two row sets:
 
       * ``det`` — THE CONTRACT METRIC: density resolved (|p_ref| > 1e-6 x its 99th percentile) and
@@ -172,6 +172,10 @@ def stats(got, want, want32, acc, seed=0):
     ok = finite & (np.abs(want) > 1e-6 * scale)
     guard = ok & (got == 0) & (want32 == 0)
     ok &= ~guard
+    n_excl = 0
+    if exclude is not None:      # disk plugins: rows within 1e-5 of the r^2 >= 0.995 guard whose decision differs (summarize())
+        n_excl = int((ok & exclude).sum())
+        ok &= ~exclude
     rel = lambda u: np.abs(u[ok] - want[ok]) / np.abs(want[ok])  # noqa: E731
     e, e32 = rel(got), rel(want32)
     okd = (np.abs(acc[ok]) > 1e-3) & (np.abs(acc[ok]) < 1e3)
@@ -180,7 +184,7 @@ def stats(got, want, want32, acc, seed=0):
     # (seen once: 1 row of 262 144 of bsdf_5_spherical, prod det J = 1.3e9, fp64 2.0e8, reference fp32 4.5e6, kernel -1.4e8)
     sign = np.sign(got[ok]) != np.sign(want[ok])
     lost32 = ~okd & ~(e32 <= 0.5)
-    out = {"nan": int((~np.isfinite(got)).sum()), "guard_rows_as_reference_fp32": int(guard.sum()),
+    out = {"nan": int((~np.isfinite(got)).sum()), "guard_rows_as_reference_fp32": int(guard.sum()), "threshold_rows": n_excl,
            "sign_mismatch": int((sign & ~lost32).sum()), "sign_mismatch_where_reference_fp32_lost": int((sign & lost32).sum()),
            "zero_mismatch": int((((got == 0) != (want == 0)) & ~guard & ((want == 0) | (np.abs(want) > 1e-30))).sum())}
     for name, sel in (("det", okd), ("all", np.ones_like(okd))):
@@ -200,10 +204,21 @@ def summarize(stem, dom, full, g, o, tiles=(32, 16)):
     seed = zlib.crc32(stem.encode())
     for tile in tiles:
         r = {}
+        # disk plugins zero a sample whose r^2 >= 0.995 (rendering/brdf_measured_disk.py:69-75): a row whose fp64 r^2 is within 1e-5 of
+        # the threshold is decided by the last bits of ANY fp32 evaluation.  Rows where kernel and oracle decide differently AND the
+        # undecided side's r^2 is that close are counted ("threshold_rows"), not scored — for sample() and the directions.
+        thr = None
+        if dom == "disk":
+            gw, ow = g[tile]["wo"].astype(np.float64), o["f64"]["wo"]
+            gz, oz = (gw[:, 0] == 0) & (gw[:, 1] == 0), (ow[:, 0] == 0) & (ow[:, 1] == 0)
+            r2 = np.where(gz, ow[:, 0] ** 2 + ow[:, 1] ** 2, gw[:, 0] ** 2 + gw[:, 1] ** 2)
+            thr = (gz != oz) & (np.abs(r2 - 0.995) < 1e-5)
         for kind in KINDS:
-            r[kind] = stats(g[tile][kind], o["f64"][kind], o["f32"][kind], o["f64"][kind + "_acc"], seed)
+            r[kind] = stats(g[tile][kind], o["f64"][kind], o["f32"][kind], o["f64"][kind + "_acc"], seed, thr if kind == "sample" else None)
         ew = np.abs(g[tile]["wo"].astype(np.float64) - o["f64"]["wo"])
         ew32 = np.abs(o["f32"]["wo"].astype(np.float64) - o["f64"]["wo"])
+        if thr is not None and thr.any():
+            ew, ew32 = ew[~thr], ew32[~thr]
         r["wo"] = {"p99": float(np.percentile(ew, 99)), "max": float(ew.max()), "ref32_p99": float(np.percentile(ew32, 99)),
                    "ref32_max": float(ew32.max())}
         row[f"tile{tile}"] = r
@@ -211,8 +226,10 @@ def summarize(stem, dom, full, g, o, tiles=(32, 16)):
 
 
 ALL_ROWS_FACTOR = 3.0   # every resolved row, near-singular steps included: at most this x the reference's own fp32 p99 (or the bound)
-# (set, tiling, call) -> cap on the upper end of the p99 interval: measured above 1e-4 where the reference's fp32 evaluation is not
-KNOWN_ABOVE_BOUND = {("cc_amber_citrine_rgb_disk", 16, "pdf_b"): 1.2e-4}
+# (set, tiling, call) -> cap on the upper end of the p99 interval: measured above 1e-4 where the reference's fp32 evaluation is not.
+# EMPTY since the 16-query kernels store the output layer's lo rows scaled (csrc/bsdfd.hip, BSDFD_WO_LO_SCALE): the one entry,
+# ("cc_amber_citrine_rgb_disk", 16, "pdf_b") at 1.05e-4 [1.02e-4, 1.08e-4], now reads 4.9e-5.
+KNOWN_ABOVE_BOUND = {}
 
 
 def verdict(row, tiles=(32, 16), stem=None):
@@ -290,6 +307,7 @@ def run(n=65536, sets=None, tiles=(32, 16), workers=None, log=print, precision="
             "worst_wo_max": max(((stem, tile, rows[stem][f"tile{tile}"]["wo"]["max"]) for stem in rows for tile in tiles), key=lambda x: x[2]),
             "median_of_p99_det": {k: float(np.median([rows[s][f"tile{t}"][k]["det"]["p99"] for s in rows for t in tiles])) for k in KINDS},
             "median_of_ref32_p99_det": {k: float(np.median([rows[s][f"tile{tiles[0]}"][k]["det"]["ref32_p99"] for s in rows])) for k in KINDS},
+            "threshold_rows": int(sum(rows[s][f"tile{t}"]["sample"].get("threshold_rows", 0) for s in rows for t in tiles)),
             "guard_rows_as_reference_fp32": int(sum(rows[s][f"tile{tiles[0]}"][k]["guard_rows_as_reference_fp32"] for s in rows for k in KINDS)),
             "sign_mismatch_where_reference_fp32_lost": {s: c for s, c in ((s, int(sum(rows[s][f"tile{t}"][k]["sign_mismatch_where_reference_fp32_lost"]
                                                                                     for t in tiles for k in KINDS))) for s in rows) if c},

@@ -38,7 +38,8 @@ def test_every_shipped_material_plugin_level_p99_interval_below_1e_4():
     # materials where the reference's OWN fp32 evaluation is above 1e-4 on the same rows (and the kernel no worse than 1.25 x it):
     # named here so that the list cannot grow unnoticed — bsdf_23 pdf() at fresh directions: reference fp32 1.5e-3, kernel 5.6e-4
     assert set(s["exempt_reference_fp32_also_above_bound"]) <= {"bsdf_23_spherical"}, s["exempt_reference_fp32_also_above_bound"]
-    # ... and the one (set, call) the 16-query tiling holds AT the bound (1.05e-4 [1.02e-4, 1.08e-4]; capped at 1.2e-4 in parity77.py)
-    assert set(s["known_above_bound_under_their_cap"]) <= {"cc_amber_citrine_rgb_disk"}, s["known_above_bound_under_their_cap"]
-    for stem, rows in s["known_above_bound_under_their_cap"].items():
-        assert all(r[0] == 16 for r in rows), (stem, rows)     # never the default tiling
+    # ... and nothing else above the bound (until round 6's scaled output-layer lo rows the 16-query tiling held one (set, call) at
+    # 1.05e-4: cc_amber_citrine_rgb_disk, pdf() at fresh directions; tests/parity77.py, KNOWN_ABOVE_BOUND)
+    assert not s["known_above_bound_under_their_cap"], s["known_above_bound_under_their_cap"]
+    # disk rows whose fp64 r^2 is within 1e-5 of the 0.995 guard and that kernel and oracle decide differently: a handful at most
+    assert s["threshold_rows"] <= 20, s["threshold_rows"]
