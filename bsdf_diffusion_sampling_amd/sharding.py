@@ -16,7 +16,7 @@ node, ``gloo`` in the CPU tests.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist

@@ -93,7 +93,6 @@ def test_config4_128Mi_mixed_queries_in_8_virtual_shards():
 
 
 def test_config5_matpreview_1024spp_as_8_row_tiles():
-    import os
     from bsdf_diffusion_sampling_amd import wavefront as WF
     from bsdf_diffusion_sampling_amd.brdf_measured_disk import MyBSDF
     _dev()

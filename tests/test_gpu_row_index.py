@@ -3,7 +3,6 @@ those rows of the callers' arrays — the gather of the inputs and the scatter o
 inside the flow kernels' own loads and stores (config 4; the dispatch it replaces: one plugin instance per material called on
 its lanes, rendering/matpreview/disney_bsdf_array0_envmap.xml + rendering/brdf_measured_disk.py:140).  Everything here is
 BIT-EXACT against the gathered / scattered form of the same calls."""
-import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu

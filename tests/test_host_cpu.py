@@ -730,7 +730,6 @@ def test_committed_profiles_match_the_kernel_source():
     """bench.py looks `roofline.traffic` (PMC passes) and the instruction-issue model (ISA of the build) up in profiles/*.json
     and withholds them when csrc/bsdfd.hip has changed since they were taken ("a kernel change without a profile
     refresh would silently carry stale figures").  The committed tree must never be in that state."""
-    import hashlib
     import json
     from bsdf_diffusion_sampling_amd import _lib
     sha = _lib.kernel_source_sha256()

@@ -12,7 +12,6 @@ no lo part) | nomfma_notrans.  Under a power cap, time x power = energy; a varia
 import os
 import subprocess
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "bsdf_diffusion_sampling_amd", "csrc")

@@ -10,7 +10,6 @@ and the backward branch to it) and prints the count per mnemonic, the issue-cycl
 of tools/ubench/RESULTS.md, and the kernel's register / scratch footprint.  Used for the
 "VALU instructions per tile-step" column of DESIGN.md §4 and the issue-bound roofline of bench.py.
 """
-import collections
 import json
 import re
 import sys

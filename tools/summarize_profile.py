@@ -109,7 +109,6 @@ def main():
     if os.path.exists(lp):
         latest = json.load(open(lp))
     if "hbm_bytes_per_launch" in out:
-        import hashlib
         import subprocess
         sys.path.insert(0, ROOT)
         from bsdf_diffusion_sampling_amd import _lib
