@@ -1,7 +1,7 @@
 // flow32.hip — the flow sampler on 32-QUERY TILES: the two nets the reference's plugins load (disk 25-32x3-2,
 // rendering/utils/model.py:479-501; spherical 26-32x4-2, :422-446; split-fp16 arithmetic) on v_mfma_f32_32x32x16_f16.
 //
-// Why a second tiling: in the VALU-heavy instruction stream of the Euler step a v_mfma_f32_16x16x32_f16 hides
+// Why a second tiling (profiles/HISTORY.md, round 5): in the VALU-heavy instruction stream of the Euler step a v_mfma_f32_16x16x32_f16 hides
 // NO other work (its 16 matrix-pipe cycles add to the VALU time), a 32x32x16 lets ~9 cycles of the co-resident waves' VALU work
 // through per instruction (tools/ubench/mfma_src, profiles/r04_ab/mfma_shapes_ubench.txt).  The 32-wide nets fit the shape exactly:
 // M = 32 = all hidden units, N = 32 queries, two K = 16 chunks per contraction — no padded rows in the hidden layers.
@@ -15,7 +15,8 @@
 //   * the query's state is DISTRIBUTED over its two lanes: lane h = 0 carries x0 (theta), lane h = 1 carries x1 (phi).  Layer 1
 //     is ONE fp16 MFMA per step: the B slots of a lane are [v_hi, v_lo, v_hi, v_lo, w_hi, w_lo, w_hi, w_lo] with (v, w) = (x0, alpha) |
 //     (x1, 0) (disk) or (theta, alpha) | (sin phi, cos phi) (spherical), the A slots [W_hi, W_hi, W_lo, W_lo] of the matching columns
-//     of W1 (all four products of the two-way splits inside one instruction), C-in = the per-query conditioning term.
+//     of W1 (all four products of the two-way splits inside one instruction; the hi parts of these state operands are ROUNDED to
+//     fp16, BSDFD_T32_L1_RN — every other split truncates), C-in = the per-query conditioning term.
 //   * the two-row output layer is an fp32 VALU dot over the lane's 16 units (the last hidden activation is never split) and one
 //     v_permlane32_swap, which leaves v0 in the lower and v1 in the upper half-wave: exactly where x0 and x1 live.
 //   * the Jacobian meets in the middle as in the 16-query kernels (MIM / MIMS); its reduction runs over the 2 lanes of a query

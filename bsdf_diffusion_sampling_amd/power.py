@@ -1,5 +1,5 @@
 """Board power of the GPU a measurement runs on — measurement plumbing shared by bench.py and tools/ab.py (no counterpart in the
-reference).  The flow kernels are POWER-limited on MI355X (socket at 1.35-1.385 kW of the 1.4 kW limit, shader
+reference).  The flow kernels are POWER-limited on MI355X (socket at 1.28-1.39 kW of the 1.4 kW limit, shader
 clock below boost), so what an optimisation buys is what it saves in joules per query; every timing is therefore reported
 next to the energy of the same launches.
 

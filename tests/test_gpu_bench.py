@@ -49,7 +49,7 @@ def test_bench_line_single_gpu_with_secondary_and_cpu_baseline():
     assert 1000 < ib["shader_clock_mhz"] < 2500, ib
     # in-kernel counters (within 1-3 % of GRBM_GUI_ACTIVE in every profiled run, profiles/r0N_*_pmc.json) vs the stand-alone probe
     # kernel, which is only reported next to them.  The probe draws little power and runs at or near the 2.4 GHz boost clock; the
-    # 32-query-tile flow kernels sit at the board's power limit and are clocked 2.06-2.15 GHz (DESIGN.md §4.5): a ratio of
+    # 32-query-tile flow kernels sit at the board's power limit and are clocked 2.06-2.15 GHz (DESIGN.md §4.3): a ratio of
     # 1.10-1.16 is the finding, not an error (it read 1.1502 on one box).  A wrong counter would be off by a factor.
     assert 0.85 < ib["probe_clock_mhz"] / ib["shader_clock_mhz"] < 1.35, ib
     # the issue model and the HBM traffic are looked up from committed profiles that carry the kernel source's fingerprint;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Where the ENERGY of the disk Euler step goes (the flow kernel is power-limited, DESIGN.md §4.5): ablated COPIES of csrc/flow32.hip
+"""Where the ENERGY of the disk Euler step goes (the flow kernel is power-limited, DESIGN.md §0, §4.3): ablated COPIES of csrc/flow32.hip
 (the product source is not touched) with one class of work removed — results are garbage, timing and clock are what is measured.
 
     python tools/energy_ablate.py build     # -> build_ab/lib_abl_<name>.so   (compiles build_ab/*.o through tools/ab_build32.sh if missing)

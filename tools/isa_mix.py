@@ -25,7 +25,7 @@ import sys
 # instructions (tools/ubench/bank); round 5 measured it IN the kernels three ways — all 97 of the disk step replaced by one
 # plain instruction each: -14 % cycles = 7.4 apiece (profiles/r05_ab/energy_ablate.jsonl); 24 v_rcp_f32 traded for 47 plain
 # instructions: +3 % time where 11 predicted -3 % (ab32_rcp_pairs.txt); the teacher's step, 384 of them, 5 240 cycles measured
-# against 6 715 by addition at 11 — and with 8.1 every kernel's measured step is within 8 % of its sum.
+# against 6 715 by addition at 11 — and with 8.1 every kernel's measured step is within 8 % of its sum (profiles/HISTORY.md, appendix §4.6).
 COST = {"v_mfma_f32_16x16x32_f16": 16.35, "v_mfma_f32_16x16x4_f32": 32.0, "v_mfma_f32_32x32x16_f16": 32.1,
         "v_exp_f32": 8.1, "v_rcp_f32": 8.1, "v_log_f32": 8.1, "v_sqrt_f32": 8.1, "v_sin_f32": 8.1, "v_cos_f32": 8.1,
         "v_rsq_f32": 8.1, "v_exp_f16": 8.1, "v_rcp_f16": 8.1,
